@@ -1,0 +1,157 @@
+/*
+ * topo_hip.h -- C ABI of libtopo_hip.so: the MI355X-native terrain render path of krzyz/topo-renderer.
+ *
+ * The reference has no FFI or plugin interface; the seam this library plugs into is the inherent-method
+ * surface of `TerrainRenderer` (topo-renderer/src/render/terrain_renderer.rs), called only from
+ * `RenderEngine` (render_engine.rs:143,160-166,183-189,212-214,276-284).  Each entry point below names the
+ * reference method it replaces; INTEGRATION.md shows the Rust `extern "C"` shim that binds them.
+ *
+ * Conventions: every function returns TOPO_OK (0) or a negative topo_status; topo_last_error() gives the
+ * text.  No exception crosses the boundary.  A context is thread-affine like the reference (all calls from
+ * the one event-loop thread; the reference keeps its shared mesh buffers in thread_local!,
+ * render_buffer.rs:12-15).  The caller keeps ownership of every input pointer; outputs are caller-allocated.
+ * There is no CPU fallback: with no HIP device every compute call fails with TOPO_ERR_HIP.
+ */
+#ifndef TOPO_HIP_H
+#define TOPO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct topo_ctx topo_ctx;
+
+typedef enum topo_status {
+    TOPO_OK = 0,
+    TOPO_ERR_INVALID = -1,     /* bad argument (null pointer, zero size, mixed tile sizes, ...) */
+    TOPO_ERR_UNSUPPORTED = -2, /* valid in the reference but outside this path (pixelize_n < 99.99999, format) */
+    TOPO_ERR_HIP = -3,         /* a HIP runtime call failed (no device, out of memory, launch failure) */
+    TOPO_ERR_NOT_FOUND = -4,   /* no such tile */
+    TOPO_ERR_CAPACITY = -5     /* draw-order id space exhausted (too many / too large tiles) */
+} topo_status;
+
+/* wgpu::TextureFormat::Rgba8UnormSrgb -- the only colour format of the headless path (render_engine.rs:77-84
+ * prefers the sRGB variant of whatever the surface offers). */
+#define TOPO_FORMAT_RGBA8_UNORM_SRGB 1u
+
+/* `Uniforms`, #[repr(C)], 160 bytes: topo-renderer/src/render/data.rs:33-41 (WGSL mirror render_shader.wgsl:3-9).
+ * Matrices are glam column-major. */
+typedef struct topo_uniforms {
+    float camera_proj[16]; /* projection * view (camera.rs:122-128) */
+    float normal_proj[16]; /* uploaded by the reference, read by no shader */
+    float camera_pos[4];   /* eye, w = 0; only .xy reaches the output (dither seed) */
+    float sun_direction[3];
+    int32_t view_mode;     /* 0 lit + dither, 1 lit, 2 normals (render_shader.wgsl:108-114) */
+} topo_uniforms;
+
+/* `PostprocessingUniforms`, 16 bytes: render/data.rs:74-80 */
+typedef struct topo_post_uniforms {
+    float viewport[2];
+    float pixelize_n; /* the reference always passes 100.0 (application_data.rs:31); < 99.99999 is rejected */
+    float _padding;
+} topo_post_uniforms;
+
+/* ---- the TerrainRenderer surface ---------------------------------------------------------------------- */
+
+/* TerrainRenderer::new(device, format, target_size)                        terrain_renderer.rs:37-69 */
+int topo_create(topo_ctx** out, int hip_device, uint32_t width, uint32_t height, uint32_t color_format);
+void topo_destroy(topo_ctx* ctx);
+
+/* TerrainRenderer::add_terrain(.., location, height_map_data, coordinate_transform, size, ..)
+ *                                                                           terrain_renderer.rs:173-350
+ * heights: w*h little-endian f32, row-major, row 0 = north (RenderBuffer::new, render_buffer.rs:76-90), host
+ * memory, borrowed for the call.  raster_point/model_point/pixel_scale: CoordinateTransform
+ * (common/coordinate_transform.rs:16-20).  Uploads, computes the interior normals and the seam/corner normals
+ * against the already loaded neighbours exactly as the reference orchestrates them.  Returns when the copy of
+ * `heights` is complete (work stays queued on the context's stream). */
+int topo_add_terrain(topo_ctx* ctx, int32_t lat_deg, int32_t lon_deg, const float* heights, uint32_t w, uint32_t h,
+                     const float raster_point[2], const float model_point[2], const float pixel_scale[2]);
+
+/* TerrainRenderer::unload_terrain(&location)                                terrain_renderer.rs:361-363 */
+int topo_unload_terrain(topo_ctx* ctx, int32_t lat_deg, int32_t lon_deg);
+
+/* TerrainRenderer::update(device, queue, target_size, &uniforms, &postprocessing_uniforms)
+ *                                                                           terrain_renderer.rs:151-171 */
+int topo_update(topo_ctx* ctx, uint32_t width, uint32_t height, const topo_uniforms* uniforms,
+                const topo_post_uniforms* post);
+
+/* TerrainRenderer::render(target, encoder, viewport) + the depth copy of RenderEngine::render
+ *                                               terrain_renderer.rs:365-452, render_engine.rs:219-249
+ * rgba_out: height rows of width RGBA8 (sRGB-encoded) texels, rgba_pitch bytes apart.  depth_out (nullable):
+ * Depth32Float rows depth_pitch bytes apart; the reference uses pad_256(4*width) (data/mod.rs:9-11).
+ * Host pointers; synchronous. */
+int topo_render(topo_ctx* ctx, uint8_t* rgba_out, size_t rgba_pitch, float* depth_out, size_t depth_pitch);
+
+const char* topo_last_error(topo_ctx* ctx);
+
+/* ---- additive entry points (no reference counterpart) ------------------------------------------------- */
+
+/* As topo_add_terrain with `heights` already in device memory (device-to-device copy). */
+int topo_add_terrain_device(topo_ctx* ctx, int32_t lat_deg, int32_t lon_deg, const float* heights_dev, uint32_t w,
+                            uint32_t h, const float raster_point[2], const float model_point[2],
+                            const float pixel_scale[2]);
+
+/* Re-runs the whole load phase (interior, seam and corner normals) over the resident heights, replaying the
+ * original insertion order.  Used to time the load phase without PCIe. */
+int topo_recompute_normals(topo_ctx* ctx);
+
+/* n_views complete reference frames (one per `views[i]`) of width x height over the loaded tiles, in one
+ * submission.  View i's image starts at rgba_dev + i*rgba_view_stride (bytes), rows rgba_pitch apart; same for
+ * depth_dev (nullable).  Device pointers; asynchronous on the context's stream.  A 360-degree panorama is
+ * 8 views of 45 degrees; with rgba_view_stride = 4*width and rgba_pitch = 4*n_views*width the
+ * views land side by side in one row-major strip. */
+int topo_render_views_device(topo_ctx* ctx, uint32_t n_views, const topo_uniforms* views, uint32_t width,
+                             uint32_t height, uint8_t* rgba_dev, size_t rgba_view_stride, size_t rgba_pitch,
+                             float* depth_dev, size_t depth_view_stride, size_t depth_pitch);
+
+/* Run the context's work on an existing hipStream_t (e.g. PyTorch's current stream); NULL restores the
+ * context's own stream. */
+int topo_set_stream(topo_ctx* ctx, void* hip_stream);
+int topo_synchronize(topo_ctx* ctx);
+
+/* LDS tile height (output rows per workgroup: 4, 8, 16, 32 or 64) of the interior-normals kernel. */
+int topo_set_normals_lds_rows(topo_ctx* ctx, int rows);
+
+/* Per-kernel durations (ms, HIP events on the context's stream) of the last topo_render* call:
+ * [0] clear  [1] cull  [2] raster  [3] raster_big  [4] resolve+post  [5] total;
+ * of the last topo_recompute_normals: [6] load phase.  Synchronises. */
+#define TOPO_TIMING_SLOTS 8
+int topo_get_timings(topo_ctx* ctx, float out_ms[TOPO_TIMING_SLOTS]);
+
+/* Counters of the last topo_render* call: [0] blocks rastered, [1] big-triangle items, [2] status bits
+ * (bit 0: big-triangle queue overflowed -- handled, slower), [3] blocks tested. */
+int topo_get_counters(topo_ctx* ctx, uint32_t out[4]);
+
+/* Test accessor: the tile's Rgba8Unorm normal texture, w*h*4 bytes, host pointer. */
+int topo_read_normals(topo_ctx* ctx, int32_t lat_deg, int32_t lon_deg, uint8_t* out);
+
+/* ---- host-side helpers mirroring the reference's CPU code ---------------------------------------------- */
+
+/* Uniforms::new(&camera, bounds) with Camera{eye, yaw, pitch, fov_y, NEAR, FAR, view_mode, sun_angle{theta,phi}}:
+ * render/data.rs:44-58, data/camera.rs:44-53,97-128 (glam 0.31 arithmetic restated in f32). */
+void topo_camera_uniforms(const float eye[3], float yaw, float pitch, float fov_y, float width, float height,
+                          float sun_theta_deg, float sun_phi_deg, int32_t view_mode, topo_uniforms* out);
+/* TerrainUniforms::new(coordinate_transform, (width, height)) -> 96 bytes (raster_point, model_point, pixel_scale,
+ * size, normal_to_world_rot column-major mat4)                              render/data.rs:113-151 */
+void topo_terrain_uniforms(const float raster_point[2], const float model_point[2], const float pixel_scale[2],
+                           uint32_t w, uint32_t h, float out24[24]);
+/* geometry::transform(h, longitude_deg, latitude_deg)                       render/geometry.rs:12-20 */
+void topo_geometry_transform(float h, float longitude_deg, float latitude_deg, float out[3]);
+/* dist_from_depth                                                           data/camera.rs:12-14 */
+float topo_dist_from_depth(float depth);
+/* pad_256                                                                   data/mod.rs:9-11 */
+uint32_t topo_pad_256(uint32_t size);
+
+/* Synthetic COP90-shaped tile for tests and benches (integer-hash fBm): w*h floats. */
+void topo_synth_tile(int32_t lat_deg, int32_t lon_deg, uint32_t w, uint32_t h, uint32_t seed, float* out);
+
+/* GPU unit-test probe: the device sin/cos of the arithmetic spec over n host floats. */
+int topo_probe_sincos(topo_ctx* ctx, const float* x, float* s, float* c, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TOPO_HIP_H */

@@ -1,0 +1,160 @@
+"""ctypes wrapper over oracle/liboracle.so -- TEST INFRASTRUCTURE ONLY (see topo_oracle.cpp header).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        L.oracle_create.restype = C.c_void_p
+        L.oracle_create.argtypes = [C.c_uint32, C.c_uint32]
+        L.oracle_destroy.argtypes = [C.c_void_p]
+        L.oracle_last_error.restype = C.c_char_p
+        L.oracle_last_error.argtypes = [C.c_void_p]
+        L.oracle_add_terrain.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_uint32, C.c_uint32,
+                                         C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_unload_terrain.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+        L.oracle_update.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.oracle_render.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.oracle_render_views.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t,
+                                          C.c_void_p, C.c_size_t, C.c_size_t, C.c_int]
+        L.oracle_read_normals.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+        L.oracle_camera_uniforms.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                             C.c_float, C.c_float, C.c_int32, C.c_void_p]
+        L.oracle_terrain_uniforms.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.oracle_geometry_transform.argtypes = [C.c_float, C.c_float, C.c_float, C.c_void_p]
+        L.oracle_dist_from_depth.restype = C.c_float
+        L.oracle_dist_from_depth.argtypes = [C.c_float]
+        L.oracle_pad_256.restype = C.c_uint32
+        L.oracle_pad_256.argtypes = [C.c_uint32]
+        L.oracle_sincos.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.oracle_srgb_tables.argtypes = [C.c_void_p, C.c_void_p]
+        L.oracle_srgb_encode.restype = C.c_uint8
+        L.oracle_srgb_encode.argtypes = [C.c_float]
+        L.oracle_vs_main_probe.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_uint32, C.c_uint32, C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def camera_uniforms(eye, yaw, pitch, fov_y, width, height, sun_theta_deg, sun_phi_deg, view_mode) -> np.ndarray:
+    out = np.zeros(40, dtype=np.float32)
+    e = np.asarray(eye, dtype=np.float32)
+    lib().oracle_camera_uniforms(_p(e), yaw, pitch, fov_y, width, height, sun_theta_deg, sun_phi_deg, view_mode, _p(out))
+    return out
+
+
+def terrain_uniforms(raster_point, model_point, pixel_scale, w, h) -> np.ndarray:
+    out = np.zeros(24, dtype=np.float32)
+    rp, mp, ps = (np.asarray(a, dtype=np.float32) for a in (raster_point, model_point, pixel_scale))
+    lib().oracle_terrain_uniforms(_p(rp), _p(mp), _p(ps), w, h, _p(out))
+    return out
+
+
+def geometry_transform(h, lon_deg, lat_deg) -> np.ndarray:
+    out = np.zeros(3, dtype=np.float32)
+    lib().oracle_geometry_transform(h, lon_deg, lat_deg, _p(out))
+    return out
+
+
+def sincos(x: np.ndarray):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    s, c = np.empty_like(x), np.empty_like(x)
+    lib().oracle_sincos(_p(x), _p(s), _p(c), x.size)
+    return s, c
+
+
+def srgb_tables():
+    d, t = np.empty(256, np.float32), np.empty(255, np.float32)
+    lib().oracle_srgb_tables(_p(d), _p(t))
+    return d, t
+
+
+def pad_256(n: int) -> int:
+    return int(lib().oracle_pad_256(n))
+
+
+class OracleRenderer:
+    """CPU restatement of TerrainRenderer (terrain_renderer.rs): new/update/add_terrain/unload_terrain/render."""
+
+    def __init__(self, width: int, height: int):
+        self._h = lib().oracle_create(width, height)
+        self.size = (width, height)
+
+    def close(self):
+        if self._h:
+            lib().oracle_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RuntimeError(lib().oracle_last_error(self._h).decode())
+
+    def add_terrain(self, lat, lon, heights, raster_point, model_point, pixel_scale):
+        hts = np.ascontiguousarray(heights, dtype=np.float32)
+        h, w = hts.shape
+        rp, mp, ps = (np.ascontiguousarray(a, dtype=np.float32) for a in (raster_point, model_point, pixel_scale))
+        self._check(lib().oracle_add_terrain(self._h, lat, lon, _p(hts), w, h, _p(rp), _p(mp), _p(ps)))
+
+    def unload_terrain(self, lat, lon):
+        self._check(lib().oracle_unload_terrain(self._h, lat, lon))
+
+    def update(self, width, height, uniforms: np.ndarray, post_uniforms: np.ndarray):
+        u = np.ascontiguousarray(uniforms).view(np.uint8)
+        pu = np.ascontiguousarray(post_uniforms, dtype=np.float32)
+        assert u.nbytes == 160 and pu.nbytes == 16
+        self._check(lib().oracle_update(self._h, width, height, _p(u), _p(pu)))
+        self.size = (width, height)
+
+    def render(self, want_pre_post=False):
+        w, h = self.size
+        rgba = np.empty((h, w, 4), np.uint8)
+        depth = np.empty((h, w), np.float32)
+        pre = np.empty((h, w, 4), np.uint8) if want_pre_post else None
+        self._check(lib().oracle_render(self._h, _p(rgba), w * 4, _p(depth), w * 4, _p(pre) if pre is not None else None))
+        return (rgba, depth, pre) if want_pre_post else (rgba, depth)
+
+    def render_views(self, uniforms_list, threads=1):
+        """n frames -> rgba (n,h,w,4), depth (n,h,w)"""
+        w, h = self.size
+        n = len(uniforms_list)
+        us = np.ascontiguousarray(np.stack([np.ascontiguousarray(u).view(np.uint8).reshape(160) for u in uniforms_list]))
+        rgba = np.empty((n, h, w, 4), np.uint8)
+        depth = np.empty((n, h, w), np.float32)
+        self._check(lib().oracle_render_views(self._h, n, _p(us), _p(rgba), w * h * 4, w * 4, _p(depth), w * h * 4, w * 4, threads))
+        return rgba, depth
+
+    def read_normals(self, lat, lon, w, h):
+        out = np.empty((h, w, 4), np.uint8)
+        self._check(lib().oracle_read_normals(self._h, lat, lon, _p(out)))
+        return out
+
+    def vs_main_probe(self, lat, lon, x, y):
+        out = np.zeros(10, np.float32)
+        lib().oracle_vs_main_probe(self._h, lat, lon, x, y, _p(out))
+        return out

@@ -1,0 +1,785 @@
+/*
+ * oracle/topo_oracle.cpp -- TEST INFRASTRUCTURE ONLY.  Never linked into, imported by or called from
+ * the product path (topo-renderer_amd/); only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may use it.
+ *
+ * PARITY UNPINNED: the reference (krzyz/topo-renderer) has no test, golden image or fixture on the
+ * terrain render path and cannot be built here (no cargo/rustc/Vulkan), so this
+ * file is a CPU restatement from the reference's source text alone.  Every function cites the
+ * reference lines it follows.  Where WebGPU/WGSL leave behaviour to the implementation (sin/cos
+ * precision, rasteriser sub-pixel grid, sRGB conversion rounding) the build freezes one definition,
+ * written down in DESIGN.md ("Arithmetic spec", "Raster spec") and restated literally here.
+ *
+ * Deliberately boring: one frame = clear, draw every tile in BTreeMap order, every triangle in
+ * index order through a classic z-buffer with the `Less` test, shade each passing fragment, then
+ * the full-screen post pass.  No binning, no culling, no deferred shading.
+ */
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "oracle_math.h"
+
+using namespace omath;
+
+namespace {
+
+/* ------------------------------------------------------------------------------------------
+ * ABI structs: topo-renderer/src/render/data.rs:33-41 (Uniforms, 160 B), :74-80
+ * (PostprocessingUniforms, 16 B), :113-121 (TerrainUniforms, 96 B).  Matrices column-major.
+ * ------------------------------------------------------------------------------------------ */
+struct Uniforms {
+    float camera_proj[16];
+    float normal_proj[16];
+    float camera_pos[4];
+    float sun_direction[3];
+    int32_t view_mode;
+};
+static_assert(sizeof(Uniforms) == 160, "Uniforms layout");
+struct PostUniforms {
+    float viewport[2];
+    float pixelize_n;
+    float pad;
+};
+static_assert(sizeof(PostUniforms) == 16, "PostprocessingUniforms layout");
+struct TerrainUniforms {
+    float raster_point[2];
+    float model_point[2];
+    float pixel_scale[2];
+    float size[2];
+    float normal_to_world_rot[16];
+};
+static_assert(sizeof(TerrainUniforms) == 96, "TerrainUniforms layout");
+
+/* ------------------------------------------------------------------------------------------
+ * sRGB conversions.  The reference gets both from the texture unit (render target and surface are
+ * *Srgb formats: render_engine.rs:77-84, terrain_renderer.rs:88-93; decode when the post pass samples
+ * t_render: postprocessing_shader.wgsl:74).  Spec: ideal IEC 61966-2-1 curve, exactly rounded.
+ * The oracle derives its own tables in long double at start-up; tests check them against the
+ * product's committed tables.
+ * ------------------------------------------------------------------------------------------ */
+struct SrgbTables {
+    float decode[256];
+    float thresh[255]; /* thresh[i-1] = smallest f32 that encodes to >= i */
+    SrgbTables() {
+        for (int c = 0; c < 256; ++c) {
+            long double s = (long double)c / 255.0L;
+            long double l = s <= 0.04045L ? s / 12.92L : powl((s + 0.055L) / 1.055L, 2.4L);
+            decode[c] = (float)l;
+        }
+        for (int i = 1; i < 256; ++i) {
+            long double s = ((long double)i - 0.5L) / 255.0L;
+            long double l = s <= 0.04045L ? s / 12.92L : powl((s + 0.055L) / 1.055L, 2.4L);
+            float f = (float)l;
+            if ((long double)f < l) f = nextafterf(f, INFINITY);
+            thresh[i - 1] = f;
+        }
+    }
+    uint8_t encode(float l) const {
+        /* number of thresholds <= l (NaN -> 0) */
+        int lo = 0, hi = 255; /* invariant: thresh[0..lo) <= l, thresh[hi..) > l */
+        while (lo < hi) {
+            int mid = (lo + hi) >> 1;
+            if (thresh[mid] <= l) lo = mid + 1; else hi = mid;
+        }
+        return (uint8_t)lo;
+    }
+};
+const SrgbTables& srgb() { static SrgbTables t; return t; }
+
+/* ------------------------------------------------------------------------------------------
+ * Tile key: BTreeMap<GeoLocation, RenderBuffer> order (terrain_renderer.rs:30,407).  GeoLocation
+ * derives Ord over {latitude{degree,direction}, longitude{degree,direction}} with S<N, W<E
+ * (topo-common/src/lib.rs:7-38); from_coord maps sign>0 to N/E, everything else to S/W (:102-121).
+ * ------------------------------------------------------------------------------------------ */
+using GeoKey = std::tuple<int, int, int, int>;
+GeoKey geo_key(int lat, int lon) {
+    return GeoKey(lat < 0 ? -lat : lat, lat > 0 ? 1 : 0, lon < 0 ? -lon : lon, lon > 0 ? 1 : 0);
+}
+
+struct Tile {
+    int lat, lon;
+    uint32_t w, h;
+    std::vector<float> hgt;   /* R32Float texture, row-major, row 0 = north (render_buffer.rs:76-90) */
+    std::vector<uint8_t> nrm; /* Rgba8Unorm, zero-initialised (texture.rs:162-199) */
+    TerrainUniforms tu;
+    float height(int x, int y) const { return hgt[(size_t)y * w + x]; }
+    void store_normal(int x, int y, v3 n) { /* textureStore(vec4(normal, 0.0)) */
+        uint8_t* p = &nrm[((size_t)y * w + x) * 4];
+        p[0] = unorm8(n.x); p[1] = unorm8(n.y); p[2] = unorm8(n.z); p[3] = unorm8(0.0f);
+    }
+};
+
+/* to_latitude: compute_normals_shader.wgsl:15-20 */
+float to_latitude(int position_y, const TerrainUniforms& t) {
+    return ((float)position_y - t.raster_point[1]) * -t.pixel_scale[1] + t.model_point[1];
+}
+/* calc_normal: compute_normals_shader.wgsl:53-58 */
+v3 calc_normal(v3 left, v3 right, v3 top, v3 bottom) {
+    v3 x = sub(right, left);
+    v3 y = sub(top, bottom);
+    return cross(x, y);
+}
+v3 encode_normal(v3 n) { /* normal = 0.5 * (normal + vec3f(1)) */
+    return {0.5f * (n.x + 1.0f), 0.5f * (n.y + 1.0f), 0.5f * (n.z + 1.0f)};
+}
+
+/* compute_normals: compute_normals_shader.wgsl:22-51 (launch: compute_pipeline.rs:64,74) */
+void normals_interior(Tile& t) {
+    const int W = (int)t.w, H = (int)t.h;
+    for (int cy = 0; cy < H; ++cy)
+        for (int cx = 0; cx < W; ++cx) {
+            if (cx >= W - 1 || cy >= H - 1 || cx < 1 || cy < 1) continue;
+            float latitude = to_latitude(cy, t.tu);
+            float x = radians(t.tu.pixel_scale[0]) * R0;
+            float y = radians(t.tu.pixel_scale[1]) * R0 * cos_spec(radians(latitude));
+            v3 top = {0.0f, y, t.height(cx, cy - 1)};
+            v3 left = {-x, 0.0f, t.height(cx - 1, cy)};
+            v3 right = {x, 0.0f, t.height(cx + 1, cy)};
+            v3 bottom = {0.0f, -y, t.height(cx, cy + 1)};
+            v3 n = normalize(calc_normal(left, right, top, bottom));
+            t.store_normal(cx, cy, encode_normal(n));
+        }
+}
+
+/* compute_normals_left_right: compute_normals_edge_shader.wgsl:25-64.  `u` is the NEWLY ADDED
+ * tile's uniforms whichever side it is on (terrain_renderer.rs:275).  The guard uses dimensions.x
+ * although the invocation index runs along y (:33); invocations that would fall outside the
+ * texture (non-square tiles only) are skipped (WebGPU drops out-of-bounds texel stores). */
+void normals_edge_lr(Tile& lt, Tile& rb, const TerrainUniforms& u) {
+    const int W = (int)lt.w, H = (int)lt.h;
+    for (int id = 0; id < W; ++id) {
+        if (id < 1 || id >= W - 1) continue;
+        if (id >= H - 1) continue;
+        float latitude = to_latitude(id, u);
+        float x = radians(fabsf(u.pixel_scale[0])) * R0;
+        float y = radians(fabsf(u.pixel_scale[1])) * R0 * cos_spec(radians(latitude));
+        const int lx = W - 1, ly = id; /* coords_left */
+        const int rx = 0, ry = id;     /* coords_right */
+        v3 top = {0.0f, y, lt.height(lx, ly - 1)};
+        v3 left = {-x, 0.0f, lt.height(lx - 1, ly)};
+        v3 right = {x, 0.0f, rb.height(rx + 1, ry)};
+        v3 bottom = {0.0f, -y, lt.height(lx, ly + 1)};
+        v3 n = encode_normal(normalize(calc_normal(left, right, top, bottom)));
+        lt.store_normal(lx, ly, n);
+        rb.store_normal(rx, ry, n);
+    }
+}
+
+/* compute_normals_top_bottom: compute_normals_edge_shader.wgsl:66-105; latitude fixed at row H-1 of
+ * the uniforms passed in (:85). */
+void normals_edge_tb(Tile& lt, Tile& rb, const TerrainUniforms& u) {
+    const int W = (int)lt.w, H = (int)lt.h;
+    for (int id = 0; id < W; ++id) {
+        if (id < 1 || id >= W - 1) continue;
+        float latitude = to_latitude(H - 1, u);
+        float x = radians(fabsf(u.pixel_scale[0])) * R0;
+        float y = radians(fabsf(u.pixel_scale[1])) * R0 * cos_spec(radians(latitude));
+        const int tx = id, ty = H - 1; /* coords_top */
+        const int bx = id, by = 0;     /* coords_bottom */
+        v3 top = {0.0f, y, lt.height(tx, ty - 1)};
+        v3 left = {-x, 0.0f, lt.height(tx - 1, ty)};
+        v3 right = {x, 0.0f, lt.height(tx + 1, ty)};
+        v3 bottom = {0.0f, -y, rb.height(bx, by + 1)};
+        v3 n = encode_normal(normalize(calc_normal(left, right, top, bottom)));
+        lt.store_normal(tx, ty, n);
+        rb.store_normal(bx, by, n);
+    }
+}
+
+/* compute_normals_corner: compute_normals_corner_shader.wgsl:29-63.  `top` is read from the
+ * bottom-right tile at (0, H-2) exactly as written (:49). */
+void normals_corner(Tile& lt, Tile& rt, Tile& lb, Tile& rb, const TerrainUniforms& u) {
+    const int W = (int)lt.w, H = (int)lt.h;
+    float latitude = to_latitude(H - 1, u);
+    float x = radians(fabsf(u.pixel_scale[0])) * R0;
+    float y = radians(fabsf(u.pixel_scale[1])) * R0 * cos_spec(radians(latitude));
+    const int tlx = W - 1, tly = H - 1; /* coords_top_left */
+    const int trx = 0, try_ = H - 1;    /* coords_top_right */
+    const int blx = W - 1, bly = 0;     /* coords_bottom_left */
+    const int brx = 0, bry = 0;         /* coords_bottom_right */
+    v3 top = {0.0f, y, rb.height(trx, try_ - 1)};
+    v3 left = {-x, 0.0f, lt.height(tlx - 1, tly)};
+    v3 right = {x, 0.0f, rt.height(trx + 1, try_)};
+    v3 bottom = {0.0f, -y, lb.height(blx, bly + 1)};
+    v3 n = encode_normal(normalize(calc_normal(left, right, top, bottom)));
+    lt.store_normal(tlx, tly, n);
+    rt.store_normal(trx, try_, n);
+    lb.store_normal(blx, bly, n);
+    rb.store_normal(brx, bry, n);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * glam 0.31.0 restatement (host side; Cargo.lock:1272-1273).  Source of the crate is not available
+ * offline; formulas are the published ones.  Host libm sinf/cosf as Rust's f32::sin_cos.
+ * ------------------------------------------------------------------------------------------ */
+float to_radians_rs(float deg) { return deg * 0.017453292519943295f; } /* f32::to_radians */
+
+/* Mat3::from_euler(EulerRot::XYZEx, a, b, c) = Rz(c)*Ry(b)*Rx(a) (extrinsic x, then y, then z),
+ * Shoemake form with i=a, j=b, h=c: used at render/data.rs:128-133 and camera.rs:46-51. */
+void mat3_from_euler_xyz_ex(float a, float b, float c, float m[9] /* column-major 3x3 */) {
+    float si = sinf(a), ci = cosf(a), sj = sinf(b), cj = cosf(b), sh = sinf(c), ch = cosf(c);
+    float cc = ci * ch, cs = ci * sh, sc = si * ch, ss = si * sh;
+    /* m(row, col) */
+    float m00 = cj * ch, m01 = sj * sc - cs, m02 = sj * cc + ss;
+    float m10 = cj * sh, m11 = sj * ss + cc, m12 = sj * cs - sc;
+    float m20 = -sj, m21 = cj * si, m22 = cj * ci;
+    m[0] = m00; m[1] = m10; m[2] = m20;
+    m[3] = m01; m[4] = m11; m[5] = m21;
+    m[6] = m02; m[7] = m12; m[8] = m22;
+}
+
+/* TerrainUniforms::new: render/data.rs:124-151 */
+TerrainUniforms terrain_uniforms_new(const float raster_point[2], const float model_point[2],
+                                     const float pixel_scale[2], uint32_t w, uint32_t h) {
+    TerrainUniforms t;
+    memset(&t, 0, sizeof t);
+    float latitude = model_point[1], longitude = model_point[0];
+    float m3[9];
+    mat3_from_euler_xyz_ex(0.0f, to_radians_rs(90.0f - latitude), to_radians_rs(longitude), m3);
+    t.raster_point[0] = raster_point[0]; t.raster_point[1] = raster_point[1];
+    t.model_point[0] = model_point[0]; t.model_point[1] = model_point[1];
+    t.pixel_scale[0] = pixel_scale[0]; t.pixel_scale[1] = pixel_scale[1];
+    t.size[0] = (float)w; t.size[1] = (float)h;
+    /* Mat4::from_mat3 */
+    for (int c = 0; c < 3; ++c)
+        for (int r = 0; r < 3; ++r) t.normal_to_world_rot[c * 4 + r] = m3[c * 3 + r];
+    t.normal_to_world_rot[15] = 1.0f;
+    return t;
+}
+
+/* geometry::transform: render/geometry.rs:12-20 */
+v3 geometry_transform(float h, float lon_deg, float lat_deg) {
+    float r = R0 + h;
+    float lon = to_radians_rs(lon_deg), lat = to_radians_rs(lat_deg);
+    return {r * cosf(lat) * cosf(lon), r * cosf(lat) * sinf(lon), r * sinf(lat)};
+}
+
+v3 glam_normalize(v3 v) { /* Vec3::normalize = self * (1 / length) */
+    float rl = 1.0f / sqrtf((v.x * v.x + v.y * v.y) + v.z * v.z);
+    return {v.x * rl, v.y * rl, v.z * rl};
+}
+
+struct quat { float x, y, z, w; };
+
+/* Quat::from_rotation_arc(from, to) */
+quat quat_from_rotation_arc(v3 from, v3 to) {
+    const float ONE_MINUS_EPS = 1.0f - 2.0f * 1.1920929e-7f;
+    float d = dot(from, to);
+    if (d > ONE_MINUS_EPS) return {0, 0, 0, 1};
+    if (d < -ONE_MINUS_EPS) {
+        /* from.any_orthonormal_vector(), rotation by pi: q = (axis*sin(pi/2), cos(pi/2)) */
+        float sign = copysignf(1.0f, from.z);
+        float a = -1.0f / (sign + from.z);
+        float b = from.x * from.y * a;
+        v3 axis = {b, sign + from.y * from.y * a, -from.y};
+        float s = sinf(3.14159265358979323846f * 0.5f), c = cosf(3.14159265358979323846f * 0.5f);
+        return {axis.x * s, axis.y * s, axis.z * s, c};
+    }
+    v3 c = cross(from, to);
+    quat q = {c.x, c.y, c.z, 1.0f + d};
+    /* Vec4 normalize, SSE2 dot4 order (x2+z2)+(y2+w2) */
+    float l2 = (q.x * q.x + q.z * q.z) + (q.y * q.y + q.w * q.w);
+    float rl = 1.0f / sqrtf(l2);
+    return {q.x * rl, q.y * rl, q.z * rl, q.w * rl};
+}
+
+/* Quat * Vec3 */
+v3 quat_mul_vec3(quat q, v3 r) {
+    float w = q.w;
+    v3 b = {q.x, q.y, q.z};
+    float b2 = dot(b, b);
+    v3 t0 = scale(r, w * w - b2);
+    v3 t1 = scale(b, dot(r, b) * 2.0f);
+    v3 t2 = scale(cross(b, r), w * 2.0f);
+    return add(add(t0, t1), t2);
+}
+
+void mat4_mul(const float* a, const float* b, float* out) { /* Mat4 * Mat4, column by column */
+    for (int c = 0; c < 4; ++c) {
+        float col[4];
+        mat4_mul_vec4(a, b[c * 4 + 0], b[c * 4 + 1], b[c * 4 + 2], b[c * 4 + 3], col);
+        memcpy(out + c * 4, col, sizeof col);
+    }
+}
+
+/* Camera::{up, direction, get_view, build_view_proj_matrix}: data/camera.rs:97-128;
+ * LightAngle::to_vec3: :44-53; Uniforms::new: render/data.rs:44-58.  normal_proj (inverse transpose
+ * of the view, camera.rs:130-132) is uploaded but never read by the shaders (render_shader.wgsl:5);
+ * the oracle fills it with the transpose of the view's rotation part extended to 4x4, which is what
+ * inverse().transpose() of a rigid transform equals up to rounding -- it does not reach any output. */
+Uniforms camera_uniforms(const float eye_in[3], float yaw, float pitch, float fov_y, float width,
+                         float height, float sun_theta_deg, float sun_phi_deg, int view_mode) {
+    Uniforms u;
+    memset(&u, 0, sizeof u);
+    v3 eye = {eye_in[0], eye_in[1], eye_in[2]};
+    v3 up = glam_normalize(eye);
+    quat rot = quat_from_rotation_arc({0.0f, -1.0f, 0.0f}, up);
+    float x = cosf(yaw) * cosf(pitch), y = sinf(pitch), z = sinf(yaw) * cosf(pitch);
+    v3 dir = quat_mul_vec3(rot, {x, y, z});
+    /* Mat4::look_to_rh(eye, dir, up) */
+    v3 f = dir;
+    v3 s = glam_normalize(cross(f, up));
+    v3 uu = cross(s, f);
+    float view[16] = {s.x, uu.x, -f.x, 0.0f, s.y, uu.y, -f.y, 0.0f, s.z, uu.z, -f.z, 0.0f,
+                      -dot(eye, s), -dot(eye, uu), dot(eye, f), 1.0f};
+    /* Mat4::perspective_rh(fov_y, aspect, near, far) */
+    float aspect = width / height;
+    float sf = sinf(0.5f * fov_y), cf = cosf(0.5f * fov_y);
+    float hh = cf / sf, ww = hh / aspect, r = FAR_Z / (NEAR_Z - FAR_Z);
+    float proj[16] = {ww, 0, 0, 0, 0, hh, 0, 0, 0, 0, r, -1.0f, 0, 0, r * NEAR_Z, 0};
+    mat4_mul(proj, view, u.camera_proj);
+    for (int c = 0; c < 3; ++c)
+        for (int rr = 0; rr < 3; ++rr) u.normal_proj[c * 4 + rr] = view[c * 4 + rr];
+    u.normal_proj[15] = 1.0f;
+    u.camera_pos[0] = eye.x; u.camera_pos[1] = eye.y; u.camera_pos[2] = eye.z; u.camera_pos[3] = 0.0f;
+    float m3[9];
+    mat3_from_euler_xyz_ex(0.0f, to_radians_rs(90.0f - sun_phi_deg), to_radians_rs(sun_theta_deg), m3);
+    u.sun_direction[0] = m3[6]; u.sun_direction[1] = m3[7]; u.sun_direction[2] = m3[8]; /* * Vec3::Z */
+    u.view_mode = view_mode;
+    return u;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Vertex stage: render_shader.wgsl:35-73.
+ * ------------------------------------------------------------------------------------------ */
+struct VSOut {
+    float clip[4];
+    v3 wpos;
+    v3 wnrm;
+};
+
+VSOut vs_main(const Tile& t, uint32_t px, uint32_t py, const Uniforms& u) {
+    VSOut o;
+    float height = t.height((int)px, (int)py);
+    /* to_model */
+    float mx = ((float)px - t.tu.raster_point[0]) * t.tu.pixel_scale[0] + t.tu.model_point[0];
+    float my = ((float)py - t.tu.raster_point[1]) * -t.tu.pixel_scale[1] + t.tu.model_point[1];
+    float longitude = radians(mx), latitude = radians(my);
+    float R = R0 + height;
+    float slat, clat, slon, clon;
+    sincos_spec(latitude, &slat, &clat);
+    sincos_spec(longitude, &slon, &clon);
+    o.wpos = {R * clat * clon, R * clat * slon, R * slat};
+    const uint8_t* n8 = &t.nrm[((size_t)py * t.w + px) * 4];
+    v3 normal = {2.0f * from_unorm8(n8[0]) - 1.0f, 2.0f * from_unorm8(n8[1]) - 1.0f,
+                 2.0f * from_unorm8(n8[2]) - 1.0f};
+    o.wnrm = mat4_mul_dir(t.tu.normal_to_world_rot, normal);
+    mat4_mul_vec4(u.camera_proj, o.wpos.x, o.wpos.y, o.wpos.z, 1.0f, o.clip);
+    return o;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Fragment stage: render_shader.wgsl:75-87 (hash/dither), :96-115 (fs_main).
+ * ------------------------------------------------------------------------------------------ */
+float hash12n(float sx, float sy) {
+    float px = fract(sx * 5.3987f), py = fract(sy * 5.4421f);
+    float d = py * (px + 21.5351f) + px * (py + 14.3137f); /* dot(p.yx, p.xy + c) */
+    px += d; py += d;
+    return fract(px * py * 95.4307f);
+}
+void fs_main(const Uniforms& u, float frag_x, float frag_y, v3 wpos, v3 wnrm, float out[4]) {
+    const float ambient_strength = 0.01f;
+    v3 sun = {u.sun_direction[0], u.sun_direction[1], u.sun_direction[2]};
+    float d = dot(normalize(wnrm), sun);
+    float diffuse_strength = 0.7f * (d > 0.0f ? d : 0.0f);
+    float result_lin = ambient_strength + diffuse_strength; /* light_color = in.color = 1 */
+    if (u.view_mode == 2) {
+        out[0] = 0.5f * (wnrm.x + 1.0f); out[1] = 0.5f * (wnrm.y + 1.0f); out[2] = 0.5f * (wnrm.z + 1.0f);
+        out[3] = 1.0f;
+    } else if (u.view_mode == 1) {
+        out[0] = out[1] = out[2] = result_lin; out[3] = 1.0f;
+    } else {
+        /* ditherRGB(result_lin, frag.xy + camera_pos.xy - world_pos.xy) */
+        float px = frag_x + u.camera_pos[0] - wpos.x, py = frag_y + u.camera_pos[1] - wpos.y;
+        float h1[3] = {hash12n(px, py), hash12n(px + 0.07f, py + 0.07f), hash12n(px + 0.11f, py + 0.11f)};
+        float qx = px + 0.13f, qy = py + 0.13f;
+        float h2[3] = {hash12n(qx, qy), hash12n(qx + 0.07f, qy + 0.07f), hash12n(qx + 0.11f, qy + 0.11f)};
+        for (int k = 0; k < 3; ++k) out[k] = result_lin + 1.0f * (h1[k] + h2[k] - 1.0f) / 255.0f;
+        out[3] = 1.0f;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * One frame (terrain_renderer.rs:365-452): clear, draws, post.
+ * ------------------------------------------------------------------------------------------ */
+struct Frame {
+    uint32_t W, H;
+    std::vector<float> depth;     /* Depth32Float, clear 1.0 (terrain_renderer.rs:392) */
+    std::vector<uint8_t> color;   /* render_texture, Rgba8UnormSrgb */
+    std::vector<uint8_t> final_;  /* surface, Rgba8UnormSrgb */
+};
+
+void store_color(Frame& f, size_t p, const float c[4]) {
+    uint8_t* o = &f.color[p * 4];
+    o[0] = srgb().encode(c[0]); o[1] = srgb().encode(c[1]); o[2] = srgb().encode(c[2]);
+    o[3] = unorm8(c[3]);
+}
+
+struct ScreenVert {
+    int64_t X, Y; /* 1/256-pixel fixed point */
+    float z, w;   /* z_ndc, w_clip */
+};
+
+/* Raster spec: viewport transform as WebGPU framebufferCoords, snap to 1/256 pixel
+ * (round-half-even), guard band |coord| <= 2^20 pixels else the triangle is discarded. */
+bool to_screen(const VSOut& v, uint32_t W, uint32_t H, ScreenVert* s) {
+    float w = v.clip[3];
+    float nx = v.clip[0] / w, ny = v.clip[1] / w, nz = v.clip[2] / w;
+    float xf = (0.5f * (nx + 1.0f)) * (float)W;
+    float yf = (0.5f * (1.0f - ny)) * (float)H;
+    if (!(fabsf(xf) <= 1048576.0f) || !(fabsf(yf) <= 1048576.0f)) return false;
+    s->X = (int64_t)rintf(xf * 256.0f);
+    s->Y = (int64_t)rintf(yf * 256.0f);
+    s->z = nz;
+    s->w = w;
+    return true;
+}
+
+static inline int64_t floor_div(int64_t a, int64_t b) { /* b > 0 */
+    int64_t q = a / b;
+    return (a % b != 0 && a < 0) ? q - 1 : q;
+}
+
+/* Fixed-function state: CCW front, back-cull, Depth32F Less + write, REPLACE (pipeline.rs:221-246). */
+void raster_triangle(Frame& f, const Uniforms& u, const VSOut& v0, const VSOut& v1, const VSOut& v2,
+                     const ScreenVert& s0, const ScreenVert& s1, const ScreenVert& s2) {
+    /* signed doubled area in y-down framebuffer space; visually counter-clockwise <=> negative */
+    int64_t area2 = (s1.X - s0.X) * (s2.Y - s0.Y) - (s1.Y - s0.Y) * (s2.X - s0.X);
+    if (area2 >= 0) return; /* back-facing or degenerate */
+    const int64_t A = -area2;
+    int64_t minX = std::min(s0.X, std::min(s1.X, s2.X)), maxX = std::max(s0.X, std::max(s1.X, s2.X));
+    int64_t minY = std::min(s0.Y, std::min(s1.Y, s2.Y)), maxY = std::max(s0.Y, std::max(s1.Y, s2.Y));
+    /* pixel centres at (px*256+128, py*256+128) */
+    int64_t x0 = std::max<int64_t>(0, floor_div(minX - 128 + 255, 256));
+    int64_t x1 = std::min<int64_t>((int64_t)f.W - 1, floor_div(maxX - 128, 256));
+    int64_t y0 = std::max<int64_t>(0, floor_div(minY - 128 + 255, 256));
+    int64_t y1 = std::min<int64_t>((int64_t)f.H - 1, floor_div(maxY - 128, 256));
+    if (x0 > x1 || y0 > y1) return;
+    /* F_ab(p) = (by-ay)(px-ax) - (bx-ax)(py-ay): >= 0 inside for this winding.
+     * Top-left rule: edge a->b owns its boundary iff it is a left edge (dy > 0) or a top edge
+     * (dy == 0 && dx < 0). */
+    struct Edge { int64_t ax, ay, dx, dy; int64_t bias; };
+    auto mk = [](const ScreenVert& a, const ScreenVert& b) {
+        Edge e{a.X, a.Y, b.X - a.X, b.Y - a.Y, 0};
+        bool top_left = (e.dy > 0) || (e.dy == 0 && e.dx < 0);
+        e.bias = top_left ? 0 : -1;
+        return e;
+    };
+    const Edge e12 = mk(s1, s2), e20 = mk(s2, s0), e01 = mk(s0, s1);
+    auto ev = [](const Edge& e, int64_t px, int64_t py) { return e.dy * (px - e.ax) - e.dx * (py - e.ay); };
+    const float fA = (float)A;
+    const float dz1 = s1.z - s0.z, dz2 = s2.z - s0.z;
+    for (int64_t py = y0; py <= y1; ++py)
+        for (int64_t px = x0; px <= x1; ++px) {
+            const int64_t cx = px * 256 + 128, cy = py * 256 + 128;
+            const int64_t F0 = ev(e12, cx, cy), F1 = ev(e20, cx, cy), F2 = ev(e01, cx, cy);
+            if (F0 + e12.bias < 0 || F1 + e20.bias < 0 || F2 + e01.bias < 0) continue;
+            const float b0 = (float)F0 / fA, b1 = (float)F1 / fA, b2 = (float)F2 / fA;
+            float z = s0.z + (b1 * dz1 + b2 * dz2);
+            if (!(z < 1.0f)) continue; /* far plane (and NaN) */
+            if (z < 0.0f) z = 0.0f;
+            const size_t p = (size_t)py * f.W + (size_t)px;
+            if (!(z < f.depth[p])) continue; /* CompareFunction::Less */
+            /* perspective-correct varyings */
+            const float q0 = b0 / s0.w, q1 = b1 / s1.w, q2 = b2 / s2.w;
+            const float qs = (q0 + q1) + q2;
+            v3 wpos, wnrm;
+            wpos.x = ((v0.wpos.x * q0 + v1.wpos.x * q1) + v2.wpos.x * q2) / qs;
+            wpos.y = ((v0.wpos.y * q0 + v1.wpos.y * q1) + v2.wpos.y * q2) / qs;
+            wpos.z = ((v0.wpos.z * q0 + v1.wpos.z * q1) + v2.wpos.z * q2) / qs;
+            wnrm.x = ((v0.wnrm.x * q0 + v1.wnrm.x * q1) + v2.wnrm.x * q2) / qs;
+            wnrm.y = ((v0.wnrm.y * q0 + v1.wnrm.y * q1) + v2.wnrm.y * q2) / qs;
+            wnrm.z = ((v0.wnrm.z * q0 + v1.wnrm.z * q1) + v2.wnrm.z * q2) / qs;
+            float c[4];
+            fs_main(u, (float)px + 0.5f, (float)py + 0.5f, wpos, wnrm, c);
+            f.depth[p] = z;
+            store_color(f, p, c);
+        }
+}
+
+VSOut lerp_vs(const VSOut& in, const VSOut& out, float t) {
+    VSOut r;
+    for (int k = 0; k < 4; ++k) r.clip[k] = in.clip[k] + t * (out.clip[k] - in.clip[k]);
+    r.clip[2] = 0.0f; /* on the near plane by construction */
+    r.wpos = add(in.wpos, scale(sub(out.wpos, in.wpos), t));
+    r.wnrm = add(in.wnrm, scale(sub(out.wnrm, in.wnrm), t));
+    return r;
+}
+
+/* Primitive clipping against the near plane z_clip >= 0 (WebGPU clip volume 0 <= z <= w; with
+ * perspective_rh z_clip >= 0 implies w >= NEAR > 0).  Sutherland-Hodgman; the intersection is always
+ * computed from the inside vertex towards the outside vertex, t = z_in / (z_in - z_out), so the two
+ * triangles sharing an edge produce the same point.  Fan-triangulated from the first emitted vertex.
+ * The far plane is applied per fragment (z < 1), x/y planes by the viewport scissor. */
+struct PV { /* post-transform vertex cache entry */
+    VSOut v;
+    ScreenVert s;
+    bool in;  /* z_clip >= 0 */
+    bool ok;  /* inside the guard band (meaningful only when in) */
+};
+PV make_pv(const VSOut& v, uint32_t W, uint32_t H) {
+    PV p;
+    p.v = v;
+    p.in = v.clip[2] >= 0.0f;
+    p.ok = p.in && to_screen(v, W, H, &p.s);
+    return p;
+}
+void draw_triangle(Frame& f, const Uniforms& u, const PV& pa, const PV& pb, const PV& pc) {
+    const VSOut &a = pa.v, &b = pb.v, &c = pc.v;
+    const VSOut* v[3] = {&a, &b, &c};
+    bool in[3] = {pa.in, pb.in, pc.in};
+    int nin = (int)in[0] + (int)in[1] + (int)in[2];
+    if (nin == 0) return; /* also rejects NaN z */
+    if (nin == 3) {
+        if (pa.ok && pb.ok && pc.ok) raster_triangle(f, u, a, b, c, pa.s, pb.s, pc.s);
+        return;
+    }
+    VSOut poly[4];
+    int n = 0;
+    for (int i = 0; i < 3; ++i) {
+        int j = (i + 1) % 3;
+        if (in[i]) poly[n++] = *v[i];
+        if (in[i] != in[j]) {
+            const VSOut& I = in[i] ? *v[i] : *v[j];
+            const VSOut& O = in[i] ? *v[j] : *v[i];
+            float t = I.clip[2] / (I.clip[2] - O.clip[2]);
+            poly[n++] = lerp_vs(I, O, t);
+        }
+    }
+    ScreenVert sp[4];
+    for (int k = 0; k < n; ++k)
+        if (!to_screen(poly[k], f.W, f.H, &sp[k])) return; /* guard band: whole primitive discarded */
+    for (int k = 1; k + 1 < n; ++k) raster_triangle(f, u, poly[0], poly[k], poly[k + 1], sp[0], sp[k], sp[k + 1]);
+}
+
+/* generate_indices: render_buffer.rs:191-219 (vertex index = i*h + j <-> texel (x=i, y=j), :185-189) */
+void draw_tile(Frame& f, const Uniforms& u, const Tile& t) {
+    /* post-transform vertex cache (vs_main is a pure function of the vertex) */
+    std::vector<PV> vs((size_t)t.w * t.h);
+    for (uint32_t i = 0; i < t.w; ++i)
+        for (uint32_t j = 0; j < t.h; ++j) vs[(size_t)i * t.h + j] = make_pv(vs_main(t, i, j, u), f.W, f.H);
+    for (uint32_t i = 0; i + 1 < t.w; ++i)
+        for (uint32_t j = 0; j + 1 < t.h; ++j) {
+            size_t index = (size_t)i * t.h + j, next = (size_t)(i + 1) * t.h + j;
+            if ((i + j) % 2 == 0) {
+                draw_triangle(f, u, vs[index], vs[index + 1], vs[next + 1]);
+                draw_triangle(f, u, vs[next + 1], vs[next], vs[index]);
+            } else {
+                draw_triangle(f, u, vs[index], vs[index + 1], vs[next]);
+                draw_triangle(f, u, vs[next + 1], vs[next], vs[index + 1]);
+            }
+        }
+}
+
+/* Post pass: postprocessing_shader.wgsl:56-96.  uv = frag.xy / viewport addresses exact texel
+ * centres (viewport == target size), so every tap is an exact texel fetch; depth taps clamp to the
+ * edge (default sampler: texture.rs:113-117).  pixelize_n >= 99.99999 (always 100 in the reference:
+ * application_data.rs:31) -- the pixelise branch is rejected at update(). */
+void post_pass(Frame& f) {
+    const int W = (int)f.W, H = (int)f.H;
+    for (int py = 0; py < H; ++py)
+        for (int px = 0; px < W; ++px) {
+            const size_t p = (size_t)py * W + px;
+            const uint8_t* c8 = &f.color[p * 4];
+            float rc[4] = {srgb().decode[c8[0]], srgb().decode[c8[1]], srgb().decode[c8[2]], from_unorm8(c8[3])};
+            float center_linear = dist_from_depth(f.depth[p]);
+            float contour = 8.0f * center_linear;
+            for (int i = -1; i <= 1; ++i)
+                for (int j = -1; j <= 1; ++j) {
+                    if (i == 0 && j == 0) continue;
+                    int sx = std::min(std::max(px + i, 0), W - 1), sy = std::min(std::max(py + j, 0), H - 1);
+                    contour -= dist_from_depth(f.depth[(size_t)sy * W + sx]);
+                }
+            float a = smoothstep(0.05f, 0.15f, contour / center_linear);
+            const float cc[4] = {0.0f, 0.0f, 0.0f, 1.0f};
+            uint8_t* o = &f.final_[p * 4];
+            o[0] = srgb().encode(mix(rc[0], cc[0], a));
+            o[1] = srgb().encode(mix(rc[1], cc[1], a));
+            o[2] = srgb().encode(mix(rc[2], cc[2], a));
+            o[3] = unorm8(mix(rc[3], cc[3], a));
+        }
+}
+
+struct Oracle {
+    uint32_t W = 0, H = 0;
+    std::map<GeoKey, std::unique_ptr<Tile>> tiles;
+    Uniforms u{};
+    PostUniforms pu{};
+    Frame frame;
+    std::string err;
+    Tile* find(int lat, int lon) {
+        auto it = tiles.find(geo_key(lat, lon));
+        return it == tiles.end() ? nullptr : it->second.get();
+    }
+};
+
+void render_frame(const Oracle& o, const Uniforms& u, Frame& f) {
+    f.W = o.W; f.H = o.H;
+    const size_t P = (size_t)o.W * o.H;
+    f.depth.assign(P, 1.0f);
+    f.color.resize(P * 4);
+    f.final_.resize(P * 4);
+    const float clear[4] = {(float)0.0, (float)0.71, (float)0.885, (float)1.0}; /* terrain_renderer.rs:379-384 */
+    for (size_t p = 0; p < P; ++p) store_color(f, p, clear);
+    for (const auto& kv : o.tiles) draw_tile(f, u, *kv.second); /* BTreeMap order, :407-420 */
+    post_pass(f);
+}
+
+void copy_out(const Frame& f, uint8_t* rgba, size_t rgba_pitch, float* depth, size_t depth_pitch,
+              uint8_t* pre_post) {
+    for (uint32_t y = 0; y < f.H; ++y) {
+        if (rgba) memcpy(rgba + (size_t)y * rgba_pitch, &f.final_[(size_t)y * f.W * 4], (size_t)f.W * 4);
+        if (depth)
+            memcpy((uint8_t*)depth + (size_t)y * depth_pitch, &f.depth[(size_t)y * f.W], (size_t)f.W * 4);
+        if (pre_post) memcpy(pre_post + (size_t)y * f.W * 4, &f.color[(size_t)y * f.W * 4], (size_t)f.W * 4);
+    }
+}
+
+}  // namespace
+
+/* ==========================================================================================
+ * C interface for ctypes (tests / smoke / cpu_baseline only).
+ * ========================================================================================== */
+extern "C" {
+
+void* oracle_create(uint32_t w, uint32_t h) {
+    Oracle* o = new Oracle();
+    o->W = w; o->H = h;
+    return o;
+}
+void oracle_destroy(void* p) { delete (Oracle*)p; }
+const char* oracle_last_error(void* p) { return ((Oracle*)p)->err.c_str(); }
+
+/* TerrainRenderer::add_terrain: terrain_renderer.rs:173-350 */
+int oracle_add_terrain(void* p, int32_t lat, int32_t lon, const float* heights, uint32_t w, uint32_t h,
+                       const float raster_point[2], const float model_point[2], const float pixel_scale[2]) {
+    Oracle& o = *(Oracle*)p;
+    if (w < 3 || h < 3) { o.err = "tile must be at least 3x3"; return -1; }
+    if (!o.tiles.empty()) {
+        const Tile& first = *o.tiles.begin()->second;
+        if (first.w != w || first.h != h) { o.err = "mixed tile sizes are rejected (render_buffer.rs:12-15)"; return -1; }
+    }
+    auto t = std::make_unique<Tile>();
+    t->lat = lat; t->lon = lon; t->w = w; t->h = h;
+    t->hgt.assign(heights, heights + (size_t)w * h);
+    t->nrm.assign((size_t)w * h * 4, 0);
+    t->tu = terrain_uniforms_new(raster_point, model_point, pixel_scale, w, h);
+    Tile& nt = *t;
+    normals_interior(nt);
+    Tile* left = o.find(lat, lon - 1);
+    Tile* right = o.find(lat, lon + 1);
+    Tile* top = o.find(lat + 1, lon);
+    Tile* bottom = o.find(lat - 1, lon);
+    Tile* top_left = o.find(lat + 1, lon - 1);
+    Tile* top_right = o.find(lat + 1, lon + 1);
+    Tile* bottom_left = o.find(lat - 1, lon - 1);
+    Tile* bottom_right = o.find(lat - 1, lon + 1);
+    if (left) normals_edge_lr(*left, nt, nt.tu);
+    if (right) normals_edge_lr(nt, *right, nt.tu);
+    if (top) normals_edge_tb(*top, nt, nt.tu);
+    if (bottom) normals_edge_tb(nt, *bottom, nt.tu);
+    if (top_left && top && left) normals_corner(*top_left, *top, *left, nt, nt.tu);
+    if (top && top_right && right) normals_corner(*top, *top_right, nt, *right, nt.tu);
+    if (left && bottom_left && bottom) normals_corner(*left, nt, *bottom_left, *bottom, nt.tu);
+    if (right && bottom && bottom_right) normals_corner(nt, *right, *bottom, *bottom_right, nt.tu);
+    o.tiles[geo_key(lat, lon)] = std::move(t); /* BTreeMap::insert replaces */
+    return 0;
+}
+
+/* unload_terrain: terrain_renderer.rs:361-363 (neighbours' seam normals are left as they are) */
+int oracle_unload_terrain(void* p, int32_t lat, int32_t lon) {
+    ((Oracle*)p)->tiles.erase(geo_key(lat, lon));
+    return 0;
+}
+
+/* update: terrain_renderer.rs:151-171 */
+int oracle_update(void* p, uint32_t w, uint32_t h, const void* uniforms160, const void* post16) {
+    Oracle& o = *(Oracle*)p;
+    PostUniforms pu;
+    memcpy(&pu, post16, sizeof pu);
+    if (pu.pixelize_n < 99.99999f) { o.err = "pixelize_n < 99.99999 is not supported"; return -2; }
+    o.W = w; o.H = h;
+    memcpy(&o.u, uniforms160, sizeof o.u);
+    o.pu = pu;
+    return 0;
+}
+
+/* render + depth copy: terrain_renderer.rs:365-452, render_engine.rs:219-249 */
+int oracle_render(void* p, uint8_t* rgba, size_t rgba_pitch, float* depth, size_t depth_pitch, uint8_t* pre_post) {
+    Oracle& o = *(Oracle*)p;
+    render_frame(o, o.u, o.frame);
+    copy_out(o.frame, rgba, rgba_pitch, depth, depth_pitch, pre_post);
+    return 0;
+}
+
+/* n independent frames over the same tile set (one per panorama sector), OpenMP over frames.
+ * Output v lands at base + v*view_stride; used for the timed CPU baseline. */
+int oracle_render_views(void* p, uint32_t n, const void* uniforms160xn, uint8_t* rgba, size_t rgba_view_stride,
+                        size_t rgba_pitch, float* depth, size_t depth_view_stride, size_t depth_pitch, int threads) {
+    Oracle& o = *(Oracle*)p;
+    const Uniforms* us = (const Uniforms*)uniforms160xn;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads > 0 ? threads : 1)
+    for (int v = 0; v < (int)n; ++v) {
+        Frame f;
+        Uniforms u;
+        memcpy(&u, &us[v], sizeof u);
+        render_frame(o, u, f);
+        copy_out(f, rgba ? rgba + (size_t)v * rgba_view_stride : nullptr, rgba_pitch,
+                 depth ? (float*)((uint8_t*)depth + (size_t)v * depth_view_stride) : nullptr, depth_pitch, nullptr);
+    }
+    return 0;
+}
+
+int oracle_read_normals(void* p, int32_t lat, int32_t lon, uint8_t* out) {
+    Oracle& o = *(Oracle*)p;
+    Tile* t = o.find(lat, lon);
+    if (!t) { o.err = "no such tile"; return -1; }
+    memcpy(out, t->nrm.data(), t->nrm.size());
+    return 0;
+}
+
+/* host-side helpers (glam restatement) */
+void oracle_camera_uniforms(const float eye[3], float yaw, float pitch, float fov_y, float width, float height,
+                            float sun_theta_deg, float sun_phi_deg, int32_t view_mode, void* out160) {
+    Uniforms u = camera_uniforms(eye, yaw, pitch, fov_y, width, height, sun_theta_deg, sun_phi_deg, view_mode);
+    memcpy(out160, &u, sizeof u);
+}
+void oracle_terrain_uniforms(const float raster_point[2], const float model_point[2], const float pixel_scale[2],
+                             uint32_t w, uint32_t h, void* out96) {
+    TerrainUniforms t = terrain_uniforms_new(raster_point, model_point, pixel_scale, w, h);
+    memcpy(out96, &t, sizeof t);
+}
+void oracle_geometry_transform(float h, float lon_deg, float lat_deg, float out[3]) {
+    v3 r = geometry_transform(h, lon_deg, lat_deg);
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+float oracle_dist_from_depth(float d) { return dist_from_depth(d); }
+uint32_t oracle_pad_256(uint32_t size) { return ((size - 1) / 256 + 1) * 256; } /* data/mod.rs:9-11 */
+
+/* math probes for cross-checking the product's device header */
+void oracle_sincos(const float* x, float* s, float* c, size_t n) {
+    for (size_t i = 0; i < n; ++i) sincos_spec(x[i], &s[i], &c[i]);
+}
+void oracle_srgb_tables(float decode[256], float thresh[255]) {
+    memcpy(decode, srgb().decode, sizeof(float) * 256);
+    memcpy(thresh, srgb().thresh, sizeof(float) * 255);
+}
+uint8_t oracle_srgb_encode(float l) { return srgb().encode(l); }
+void oracle_vs_main_probe(void* p, int32_t lat, int32_t lon, uint32_t x, uint32_t y, float out[10]) {
+    Oracle& o = *(Oracle*)p;
+    Tile* t = o.find(lat, lon);
+    if (!t) return;
+    VSOut v = vs_main(*t, x, y, o.u);
+    memcpy(out, v.clip, 16);
+    out[4] = v.wpos.x; out[5] = v.wpos.y; out[6] = v.wpos.z;
+    out[7] = v.wnrm.x; out[8] = v.wnrm.y; out[9] = v.wnrm.z;
+}
+
+}  // extern "C"

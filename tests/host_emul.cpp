@@ -1,0 +1,169 @@
+// tests/host_emul.cpp -- TEST-ONLY g++ build of the product's TOPO_HD pipeline functions
+// (topo-renderer_amd/csrc/topo_math.h, topo_pipeline.h), driven by sequential loops that mirror the
+// HIP kernels' structure.  It lets the CPU test-suite check the product's arithmetic against the oracle
+// bit for bit without a GPU.  It is NOT a fallback: nothing in the product links or loads it, and
+// libtopo_hip.so refuses to work without a HIP device.
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../topo-renderer_amd/csrc/topo_pipeline.h"
+
+using namespace topo;
+
+extern "C" {
+
+struct EmulTile {
+    const float* heights;
+    uint32_t* normals;
+    float tu[24];   // TerrainUniforms, 96 B
+};
+
+static TileDev make_dev(const EmulTile& e) {
+    TileDev t{};
+    t.heights = e.heights; t.normals = e.normals; t.block_minmax = nullptr;
+    t.raster_x = e.tu[0]; t.raster_y = e.tu[1]; t.model_x = e.tu[2]; t.model_y = e.tu[3];
+    t.scale_x = e.tu[4]; t.scale_y = e.tu[5];
+    for (int c = 0; c < 3; ++c) for (int r = 0; r < 3; ++r) t.rot[c * 3 + r] = e.tu[8 + c * 4 + r];
+    return t;
+}
+
+void emul_sincos(const float* x, float* s, float* c, size_t n) { for (size_t i = 0; i < n; ++i) sincos_f(x[i], s[i], c[i]); }
+
+void emul_normals_interior(const EmulTile* e, int W, int H) {
+    TileDev t = make_dev(*e);
+    const float xs = deg2rad(t.scale_x) * kR0, ys0 = deg2rad(t.scale_y) * kR0;
+    for (int gy = 1; gy < H - 1; ++gy) for (int gx = 1; gx < W - 1; ++gx) {
+        const float latitude = ((float)gy - t.raster_y) * -t.scale_y + t.model_y;
+        const float ys = ys0 * cos_f(deg2rad(latitude));
+        const float* h = t.heights;
+        t.normals[(size_t)gy * W + gx] = normal_texel(xs, ys, h[(size_t)(gy - 1) * W + gx], h[(size_t)gy * W + gx - 1],
+                                                      h[(size_t)gy * W + gx + 1], h[(size_t)(gy + 1) * W + gx]);
+    }
+}
+
+void emul_normals_edge(const EmulTile* elt, const EmulTile* erb, const EmulTile* euni, int W, int H, int top_bottom) {
+    TileDev lt = make_dev(*elt), rb = make_dev(*erb), u = make_dev(*euni);
+    const float xs = deg2rad(fabsf(u.scale_x)) * kR0, ys0 = deg2rad(fabsf(u.scale_y)) * kR0;
+    for (int id = 1; id < W - 1; ++id) {
+        if (!top_bottom) {
+            if (id >= H - 1) continue;
+            const float latitude = ((float)id - u.raster_y) * -u.scale_y + u.model_y;
+            const float ys = ys0 * cos_f(deg2rad(latitude));
+            const int lx = W - 1, ly = id;
+            const uint32_t tx = normal_texel(xs, ys, lt.heights[(size_t)(ly - 1) * W + lx], lt.heights[(size_t)ly * W + lx - 1],
+                                             rb.heights[(size_t)id * W + 1], lt.heights[(size_t)(ly + 1) * W + lx]);
+            lt.normals[(size_t)ly * W + lx] = tx; rb.normals[(size_t)id * W] = tx;
+        } else {
+            const float latitude = ((float)(H - 1) - u.raster_y) * -u.scale_y + u.model_y;
+            const float ys = ys0 * cos_f(deg2rad(latitude));
+            const int ty = H - 1;
+            const uint32_t tx = normal_texel(xs, ys, lt.heights[(size_t)(ty - 1) * W + id], lt.heights[(size_t)ty * W + id - 1],
+                                             lt.heights[(size_t)ty * W + id + 1], rb.heights[(size_t)W + id]);
+            lt.normals[(size_t)ty * W + id] = tx; rb.normals[id] = tx;
+        }
+    }
+}
+
+void emul_normals_corner(const EmulTile* elt, const EmulTile* ert, const EmulTile* elb, const EmulTile* erb,
+                         const EmulTile* euni, int W, int H) {
+    TileDev lt = make_dev(*elt), rt = make_dev(*ert), lb = make_dev(*elb), rb = make_dev(*erb), u = make_dev(*euni);
+    const float latitude = ((float)(H - 1) - u.raster_y) * -u.scale_y + u.model_y;
+    const float xs = deg2rad(fabsf(u.scale_x)) * kR0;
+    const float ys = deg2rad(fabsf(u.scale_y)) * kR0 * cos_f(deg2rad(latitude));
+    const uint32_t tx = normal_texel(xs, ys, rb.heights[(size_t)(H - 2) * W], lt.heights[(size_t)(H - 1) * W + W - 2],
+                                     rt.heights[(size_t)(H - 1) * W + 1], lb.heights[(size_t)W + W - 1]);
+    lt.normals[(size_t)(H - 1) * W + W - 1] = tx; rt.normals[(size_t)(H - 1) * W] = tx; lb.normals[W - 1] = tx; rb.normals[0] = tx;
+}
+
+static void emul_emit(const TriSetup& ts, uint64_t* vis, int W, uint32_t id) {
+    for (int py = ts.py0; py <= ts.py1; ++py) for (int px = ts.px0; px <= ts.px1; ++px) {
+        float z, b[3];
+        if (triangle_pixel(ts, px, py, z, b)) {
+            const uint64_t key = vis_key(z, id);
+            if (key < vis[(size_t)py * W + px]) vis[(size_t)py * W + px] = key;
+        }
+    }
+}
+
+// tiles must be given in draw (BTreeMap) order
+int emul_render(const EmulTile* tiles, uint32_t n_tiles, uint32_t tile_w, uint32_t tile_h, const float* uniforms40,
+                int W, int H, uint8_t* rgba, float* depth) {
+    ViewDev view{};
+    memcpy(view.proj, uniforms40, 64);
+    view.cam_x = uniforms40[32]; view.cam_y = uniforms40[33];
+    memcpy(view.sun, uniforms40 + 36, 12);
+    memcpy(&view.view_mode, uniforms40 + 39, 4);
+    std::vector<TileDev> td;
+    for (uint32_t i = 0; i < n_tiles; ++i) td.push_back(make_dev(tiles[i]));
+    std::vector<uint64_t> vis((size_t)W * H, kVisClear);
+    const uint32_t tris_per_tile = 2u * (tile_w - 1) * (tile_h - 1);
+    for (uint32_t rank = 0; rank < n_tiles; ++rank) {
+        const TileDev& t = td[rank];
+        std::vector<SVert> sv((size_t)tile_w * tile_h);
+        for (uint32_t vy = 0; vy < tile_h; ++vy) for (uint32_t vx = 0; vx < tile_w; ++vx) {
+            float clip[4];
+            vertex_clip(t, view, vx, vy, t.heights[(size_t)vy * tile_w + vx], clip);
+            clip_to_screen(clip, (float)W, (float)H, sv[(size_t)vy * tile_w + vx]);
+        }
+        for (uint32_t i = 0; i + 1 < tile_w; ++i) for (uint32_t j = 0; j + 1 < tile_h; ++j) {
+            const SVert a = sv[(size_t)j * tile_w + i], b = sv[(size_t)(j + 1) * tile_w + i];
+            const SVert c = sv[(size_t)j * tile_w + i + 1], d = sv[(size_t)(j + 1) * tile_w + i + 1];
+            const bool even = ((i + j) & 1u) == 0;
+            for (uint32_t k = 0; k < 2; ++k) {
+                const SVert& s0 = k == 0 ? a : d;
+                const SVert& s1 = k == 0 ? b : c;
+                const SVert& s2 = k == 0 ? (even ? d : c) : (even ? a : b);
+                const uint32_t tri = (i * (tile_h - 1) + j) * 2 + k, draw = rank * tris_per_tile + tri;
+                const int nnear = (s0.flag == kVtxNear) + (s1.flag == kVtxNear) + (s2.flag == kVtxNear);
+                if (nnear == 3) continue;
+                if (nnear != 0) {
+                    for (uint32_t fan = 0; fan < 2; ++fan) {
+                        ResolvedTri r;
+                        if (resolve_triangle(t, tile_w, tile_h, view, W, H, tri, fan, r)) emul_emit(r.ts, vis.data(), W, (draw << 1) | fan);
+                    }
+                    continue;
+                }
+                if ((s0.flag | s1.flag | s2.flag) != kVtxOk) continue;
+                TriSetup ts;
+                if (triangle_setup(s0, s1, s2, W, H, ts)) emul_emit(ts, vis.data(), W, draw << 1);
+            }
+        }
+    }
+    float thresh[256], decode[256];
+    for (int i = 0; i < 256; ++i) { thresh[i] = bits_f(TOPO_SRGB_THRESH_BITS[i]); decode[i] = bits_f(TOPO_SRGB_DECODE_BITS[i]); }
+    auto vdepth = [&](int x, int y) {
+        x = x < 0 ? 0 : (x > W - 1 ? W - 1 : x); y = y < 0 ? 0 : (y > H - 1 ? H - 1 : y);
+        return bits_f((uint32_t)(vis[(size_t)y * W + x] >> 32));
+    };
+    for (int py = 0; py < H; ++py) for (int px = 0; px < W; ++px) {
+        const uint64_t key = vis[(size_t)py * W + px];
+        const float dc = bits_f((uint32_t)(key >> 32));
+        const uint32_t id = (uint32_t)key;
+        float lin[4] = {0.0f, 0.71f, 0.885f, 1.0f};
+        if (id != kNoTri) {
+            const uint32_t draw = id >> 1, fan = id & 1u, rank = draw / tris_per_tile, tri = draw - rank * tris_per_tile;
+            ResolvedTri r; float z, b[3];
+            if (!(resolve_triangle(td[rank], tile_w, tile_h, view, W, H, tri, fan, r) && triangle_pixel(r.ts, px, py, z, b))) return -1;
+            f3 wpos, wnrm;
+            interpolate(r.v[0], r.v[1], r.v[2], b, wpos, wnrm);
+            shade_fragment(view.view_mode, {view.sun[0], view.sun[1], view.sun[2]}, view.cam_x, view.cam_y, (float)px + 0.5f,
+                           (float)py + 0.5f, wpos, wnrm, lin);
+        }
+        const uint32_t c8 = srgb_encode(thresh, lin[0]) | (srgb_encode(thresh, lin[1]) << 8) | (srgb_encode(thresh, lin[2]) << 16) |
+                            (to_unorm8(lin[3]) << 24);
+        float dn[8]; int k = 0;
+        for (int i = -1; i <= 1; ++i) for (int j = -1; j <= 1; ++j) { if (i == 0 && j == 0) continue; dn[k++] = vdepth(px + i, py + j); }
+        const uint32_t o = post_pixel(thresh, decode, c8, dc, dn);
+        memcpy(rgba + ((size_t)py * W + px) * 4, &o, 4);
+        depth[(size_t)py * W + px] = dc;
+    }
+    return 0;
+}
+
+void emul_srgb_tables(float* decode, float* thresh) {
+    for (int i = 0; i < 256; ++i) decode[i] = bits_f(TOPO_SRGB_DECODE_BITS[i]);
+    for (int i = 0; i < 255; ++i) thresh[i] = bits_f(TOPO_SRGB_THRESH_BITS[i]);
+}
+
+}  // extern "C"

@@ -1,0 +1,149 @@
+"""GPU parity: the HIP path through the C ABI (libtopo_hip.so) against the CPU oracle, bit for bit.
+
+Depth is compared as raw f32 bits (north_star tolerance: 1 ULP -- we hold 0), colour as RGBA8 bytes
+(tolerance: 1 LSB -- we hold 0)."""
+import math
+
+import numpy as np
+import pytest
+
+from scenes import Scene, assert_same_frame
+
+pytestmark = pytest.mark.gpu
+
+
+def both(topo, orc, W, H):
+    return topo.TerrainRenderer(W, H), orc.OracleRenderer(W, H)
+
+
+def test_device_sincos_matches_spec(topo, orc):
+    r = topo.TerrainRenderer(8, 8)
+    rng = np.random.default_rng(1)
+    x = np.concatenate([rng.uniform(-3.2, 3.2, 200000), np.linspace(-7, 7, 50001), [0.0, -0.0, math.pi / 4, -math.pi / 4]]).astype(np.float32)
+    s, c = r.probe_sincos(x)
+    so, co = orc.sincos(x)
+    assert np.array_equal(s.view(np.uint32), so.view(np.uint32))
+    assert np.array_equal(c.view(np.uint32), co.view(np.uint32))
+    assert np.abs(s - np.sin(x.astype(np.float64))).max() < 2e-7
+
+
+@pytest.mark.parametrize("tile,n_lat,n_lon", [(64, 1, 1), (48, 2, 2), (33, 3, 3), (150, 1, 2)])
+def test_normals_byte_exact(topo, orc, tile, n_lat, n_lon):
+    sc = Scene(tile, n_lat, n_lon)
+    g, o = both(topo, orc, 16, 16)
+    sc.load(g)
+    sc.load(o)
+    for loc in sc.locs:
+        a, b = g.read_normals(*loc), o.read_normals(loc[0], loc[1], tile, tile)
+        assert np.array_equal(a, b), f"tile {loc}: {np.argwhere((a != b).any(axis=-1))[:4]}"
+
+
+def test_normals_insertion_order_and_unload(topo, orc):
+    sc = Scene(40, 2, 2)
+    order = [sc.locs[3], sc.locs[0], sc.locs[2], sc.locs[1]]
+    g, o = both(topo, orc, 16, 16)
+    sc.load(g, order)
+    sc.load(o, order)
+    g.unload_terrain(*order[1])
+    o.unload_terrain(*order[1])
+    g.add_terrain(order[1][0], order[1][1], sc.heights[order[1]], *sc.transform(order[1]))
+    o.add_terrain(order[1][0], order[1][1], sc.heights[order[1]], *sc.transform(order[1]))
+    for loc in sc.locs:
+        assert np.array_equal(g.read_normals(*loc), o.read_normals(loc[0], loc[1], 40, 40))
+    g.recompute_normals()   # replay of the load phase must not change the state when nothing was unloaded since
+    g2, _ = both(topo, orc, 16, 16)
+    sc.load(g2, order)
+    g2.recompute_normals()
+    o2 = orc.OracleRenderer(16, 16)
+    sc.load(o2, order)
+    for loc in sc.locs:
+        assert np.array_equal(g2.read_normals(*loc), o2.read_normals(loc[0], loc[1], 40, 40))
+
+
+FRAMES = [
+    # tile, n_lat, n_lon, W, H, yaw, pitch, fov, mode, eye_dh
+    (64, 1, 1, 128, 64, 0, 0, 60, 0, 50),
+    (64, 1, 1, 128, 64, 0, 0, 60, 1, 50),
+    (64, 1, 1, 128, 64, 0, 0, 60, 2, 50),
+    (64, 2, 2, 128, 64, 30, 10, 60, 0, 50),
+    (48, 3, 3, 160, 96, 200, 30, 79.28, 0, 50),
+    (128, 2, 2, 256, 128, 123, -5, 45, 0, 50),
+    (64, 2, 2, 128, 128, 77, 60, 100, 0, 100),     # big near-field triangles, near-plane clipping
+    (64, 2, 2, 128, 128, 77, 85, 100, 1, 400),
+    (256, 1, 1, 300, 200, 10, 45, 90, 0, 20),
+    (200, 1, 2, 257, 131, 300, 20, 120, 2, 80),     # odd sizes
+]
+
+
+@pytest.mark.parametrize("cfg", FRAMES, ids=[f"f{i}" for i in range(len(FRAMES))])
+def test_frame_bit_exact(topo, orc, cfg):
+    tile, n_lat, n_lon, W, H, yaw, pitch, fov, mode, dh = cfg
+    sc = Scene(tile, n_lat, n_lon, eye_dh=dh)
+    g, o = both(topo, orc, W, H)
+    sc.load(g)
+    sc.load(o)
+    u, pu = sc.uniforms(W, H, yaw, pitch, fov, mode), topo.post_uniforms(W, H)
+    g.update(W, H, u, pu)
+    o.update(W, H, u, pu)
+    assert_same_frame(g.render(), o.render(), f"frame {cfg}")
+    assert (g.counters()["status"] & 1) == 0
+
+
+def test_depth_pitch_pad_256(topo, orc):
+    sc = Scene(64, 1, 1)
+    W, H = 100, 40
+    g, o = both(topo, orc, W, H)
+    sc.load(g)
+    sc.load(o)
+    u, pu = sc.uniforms(W, H, 45, 20, 70), topo.post_uniforms(W, H)
+    g.update(W, H, u, pu)
+    o.update(W, H, u, pu)
+    rgba, depth = g.render(padded_depth=True)
+    assert depth.shape[1] * 4 == topo.pad_256(4 * W) == 512
+    ro, do = o.render()
+    assert np.array_equal(depth[:, :W].view(np.uint32), do.view(np.uint32))
+    assert np.array_equal(rgba, ro)
+
+
+def test_empty_scene_is_sky(topo, orc):
+    g, o = both(topo, orc, 64, 32)
+    sc = Scene(16, 1, 1)
+    u, pu = sc.uniforms(64, 32), topo.post_uniforms(64, 32)
+    g.update(64, 32, u, pu)
+    o.update(64, 32, u, pu)
+    assert_same_frame(g.render(), o.render(), "empty scene")
+    g.add_terrain(45, 15, sc.heights[(45, 15)], *sc.transform((45, 15)))
+    g.unload_terrain(45, 15)
+    assert_same_frame(g.render(), o.render(), "after unload")
+
+
+def test_errors_mirror_reference_limits(topo):
+    g = topo.TerrainRenderer(32, 32)
+    sc = Scene(16, 1, 1)
+    g.add_terrain(45, 15, sc.heights[(45, 15)], *sc.transform((45, 15)))
+    with pytest.raises(topo.TopoError) as e:
+        g.add_terrain(45, 16, np.zeros((20, 20), np.float32), *sc.transform((45, 16)))
+    assert e.value.code == topo.TOPO_ERR_INVALID
+    with pytest.raises(topo.TopoError) as e:
+        g.update(32, 32, sc.uniforms(32, 32), topo.post_uniforms(32, 32, pixelize_n=50.0))
+    assert e.value.code == topo.TOPO_ERR_UNSUPPORTED
+
+
+def test_panorama_views_match_per_sector_frames(topo, orc):
+    import torch
+    sc = Scene(96, 2, 2)
+    sw, sh = 64, 128
+    g, o = both(topo, orc, sw, sh)
+    sc.load(g)
+    sc.load(o)
+    us = sc.panorama(sw, sh, yaw0_deg=11.0)
+    strip = torch.zeros((sh, 8 * sw, 4), dtype=torch.uint8, device="cuda")
+    depth = torch.zeros((sh, 8 * sw), dtype=torch.float32, device="cuda")
+    g.set_stream(torch.cuda.current_stream().cuda_stream)
+    g.render_views_device(us, sw, sh, strip.data_ptr(), 4 * sw, 4 * 8 * sw, depth.data_ptr(), 4 * sw, 4 * 8 * sw)
+    torch.cuda.synchronize()
+    strip, depth = strip.cpu().numpy(), depth.cpu().numpy()
+    o.update(sw, sh, us[0], topo.post_uniforms(sw, sh))
+    ro, do = o.render_views(us, threads=4)
+    for k in range(8):
+        assert_same_frame((strip[:, k * sw:(k + 1) * sw], depth[:, k * sw:(k + 1) * sw]), (ro[k], do[k]), f"sector {k}")

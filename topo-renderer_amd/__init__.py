@@ -1,0 +1,261 @@
+"""topo-renderer_amd -- MI355X-native terrain-panorama render path of krzyz/topo-renderer.
+
+Python is only the test/bench binding here: the product is `libtopo_hip.so` (hand-written gfx950 HIP kernels
+behind the C ABI of include/topo_hip.h, host orchestration in C++).  This module mirrors the reference's
+`TerrainRenderer` method set (topo-renderer/src/render/terrain_renderer.rs: new / update / add_terrain /
+unload_terrain / render) over ctypes.
+
+The directory name carries a hyphen, so it is imported through the loader `topo_renderer_amd.py` at the
+repository root (``import topo_renderer_amd``).
+
+There is no CPU fallback: if the shared library is missing, or no HIP device is present, calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+import subprocess
+
+import numpy as np
+
+from . import synth  # noqa: F401  (re-exported)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtopo_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "topo_hip.h")
+
+TOPO_OK = 0
+TOPO_ERR_INVALID, TOPO_ERR_UNSUPPORTED, TOPO_ERR_HIP, TOPO_ERR_NOT_FOUND, TOPO_ERR_CAPACITY = -1, -2, -3, -4, -5
+FORMAT_RGBA8_UNORM_SRGB = 1
+TIMING_SLOTS = 8
+TIMING_NAMES = ("clear", "cull", "raster", "raster_big", "resolve", "total", "load", "_")
+
+NEAR, FAR = 50.0, 500000.0           # data/camera.rs:6-7
+N_SECTORS = 8                        # fixed panorama sector count
+
+
+class TopoError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"topo_hip error {code}: {msg}")
+        self.code = code
+
+
+def build(verbose: bool = False) -> str:
+    """Compile libtopo_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc")] + ([] if verbose else ["-s"]))
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """The loaded C ABI.  Fails loudly when the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(there is no Python/CPU fallback for the render path)")
+        L = C.CDLL(LIB_PATH)
+        vp, u32, i32, f32, sz = C.c_void_p, C.c_uint32, C.c_int32, C.c_float, C.c_size_t
+        sigs = {
+            "topo_create": (C.c_int, [C.POINTER(vp), C.c_int, u32, u32, u32]),
+            "topo_destroy": (None, [vp]),
+            "topo_last_error": (C.c_char_p, [vp]),
+            "topo_add_terrain": (C.c_int, [vp, i32, i32, vp, u32, u32, vp, vp, vp]),
+            "topo_add_terrain_device": (C.c_int, [vp, i32, i32, vp, u32, u32, vp, vp, vp]),
+            "topo_unload_terrain": (C.c_int, [vp, i32, i32]),
+            "topo_update": (C.c_int, [vp, u32, u32, vp, vp]),
+            "topo_render": (C.c_int, [vp, vp, sz, vp, sz]),
+            "topo_recompute_normals": (C.c_int, [vp]),
+            "topo_render_views_device": (C.c_int, [vp, u32, vp, u32, u32, vp, sz, sz, vp, sz, sz]),
+            "topo_set_stream": (C.c_int, [vp, vp]),
+            "topo_synchronize": (C.c_int, [vp]),
+            "topo_set_normals_lds_rows": (C.c_int, [vp, C.c_int]),
+            "topo_get_timings": (C.c_int, [vp, vp]),
+            "topo_get_counters": (C.c_int, [vp, vp]),
+            "topo_read_normals": (C.c_int, [vp, i32, i32, vp]),
+            "topo_probe_sincos": (C.c_int, [vp, vp, vp, vp, sz]),
+            "topo_camera_uniforms": (None, [vp, f32, f32, f32, f32, f32, f32, f32, i32, vp]),
+            "topo_terrain_uniforms": (None, [vp, vp, vp, u32, u32, vp]),
+            "topo_geometry_transform": (None, [f32, f32, f32, vp]),
+            "topo_dist_from_depth": (f32, [f32]),
+            "topo_pad_256": (u32, [u32]),
+            "topo_synth_tile": (None, [i32, i32, u32, u32, u32, vp]),
+        }
+        for name, (res, args) in sigs.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        L._topo_symbols = tuple(sigs)
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+# ---- host-side helpers (reference CPU code restated in the library) ------------------------------------
+
+def camera_uniforms(eye, yaw, pitch, fov_y, width, height, sun_theta_deg, sun_phi_deg, view_mode=0) -> np.ndarray:
+    """Uniforms::new(&camera, bounds) -> 40 x f32 view of the 160-byte struct (render/data.rs:33-58)."""
+    out = np.zeros(40, dtype=np.float32)
+    e = np.ascontiguousarray(eye, dtype=np.float32)
+    lib().topo_camera_uniforms(_p(e), yaw, pitch, fov_y, width, height, sun_theta_deg, sun_phi_deg, view_mode, _p(out))
+    return out
+
+
+def terrain_uniforms(raster_point, model_point, pixel_scale, w, h) -> np.ndarray:
+    out = np.zeros(24, dtype=np.float32)
+    rp, mp, ps = (np.ascontiguousarray(a, dtype=np.float32) for a in (raster_point, model_point, pixel_scale))
+    lib().topo_terrain_uniforms(_p(rp), _p(mp), _p(ps), w, h, _p(out))
+    return out
+
+
+def geometry_transform(h, lon_deg, lat_deg) -> np.ndarray:
+    out = np.zeros(3, dtype=np.float32)
+    lib().topo_geometry_transform(h, lon_deg, lat_deg, _p(out))
+    return out
+
+
+def dist_from_depth(d: float) -> float:
+    return float(lib().topo_dist_from_depth(d))
+
+
+def pad_256(n: int) -> int:
+    return int(lib().topo_pad_256(n))
+
+
+def synth_tile(lat_deg, lon_deg, w=1200, h=1200, seed=synth.SEED_DEFAULT) -> np.ndarray:
+    """C++ twin of synth.synth_tile (bit-identical, ~50x faster)."""
+    out = np.empty((h, w), dtype=np.float32)
+    lib().topo_synth_tile(lat_deg, lon_deg, w, h, seed & 0xFFFFFFFF, _p(out))
+    return out
+
+
+def post_uniforms(width, height, pixelize_n=100.0) -> np.ndarray:
+    """PostprocessingUniforms::new (render/data.rs:82-89)."""
+    return np.array([width, height, pixelize_n, 0.0], dtype=np.float32)
+
+
+def sector_fov_y(sector_w: int, sector_h: int, n_sectors: int = N_SECTORS) -> float:
+    """Vertical FOV that gives each sector a horizontal FOV of 360/n degrees."""
+    return 2.0 * math.atan(math.tan(math.pi / n_sectors) * sector_h / sector_w)
+
+
+def panorama_uniforms(eye, yaw0, sector_w, sector_h, sun_theta_deg, sun_phi_deg, view_mode=0,
+                      n_sectors: int = N_SECTORS, pitch: float = 0.0):
+    """The n_sectors reference cameras of a 360-degree strip: sector k looks at yaw0 + k*(360/n) degrees."""
+    fov = sector_fov_y(sector_w, sector_h, n_sectors)
+    return [camera_uniforms(eye, yaw0 + k * (2.0 * math.pi / n_sectors), pitch, fov, sector_w, sector_h,
+                            sun_theta_deg, sun_phi_deg, view_mode) for k in range(n_sectors)]
+
+
+# ---- the TerrainRenderer mirror ------------------------------------------------------------------------
+
+class TerrainRenderer:
+    """Mirror of the reference's TerrainRenderer (terrain_renderer.rs) on one MI355X."""
+
+    def __init__(self, width: int, height: int, device: int = 0, color_format: int = FORMAT_RGBA8_UNORM_SRGB):
+        h = C.c_void_p()
+        rc = lib().topo_create(C.byref(h), device, width, height, color_format)
+        if rc != TOPO_OK:
+            raise TopoError(rc, lib().topo_last_error(None).decode())
+        self._h = h
+        self.size = (width, height)
+        self.tile_size = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().topo_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != TOPO_OK:
+            raise TopoError(rc, lib().topo_last_error(self._h).decode())
+
+    # add_terrain(location, height_map_data, coordinate_transform, size)   terrain_renderer.rs:173-182
+    def add_terrain(self, lat_deg, lon_deg, heights, raster_point, model_point, pixel_scale):
+        hts = np.ascontiguousarray(heights, dtype=np.float32)
+        h, w = hts.shape
+        rp, mp, ps = (np.ascontiguousarray(a, dtype=np.float32) for a in (raster_point, model_point, pixel_scale))
+        self._check(lib().topo_add_terrain(self._h, lat_deg, lon_deg, _p(hts), w, h, _p(rp), _p(mp), _p(ps)))
+        self.tile_size = (w, h)
+
+    def add_terrain_device(self, lat_deg, lon_deg, heights_ptr: int, w, h, raster_point, model_point, pixel_scale):
+        rp, mp, ps = (np.ascontiguousarray(a, dtype=np.float32) for a in (raster_point, model_point, pixel_scale))
+        self._check(lib().topo_add_terrain_device(self._h, lat_deg, lon_deg, C.c_void_p(heights_ptr), w, h, _p(rp), _p(mp), _p(ps)))
+        self.tile_size = (w, h)
+
+    def unload_terrain(self, lat_deg, lon_deg):
+        self._check(lib().topo_unload_terrain(self._h, lat_deg, lon_deg))
+
+    # update(target_size, &uniforms, &postprocessing_uniforms)              terrain_renderer.rs:151-158
+    def update(self, width, height, uniforms: np.ndarray, post: np.ndarray):
+        u = np.ascontiguousarray(uniforms).view(np.uint8)
+        pu = np.ascontiguousarray(post, dtype=np.float32)
+        if u.nbytes != 160 or pu.nbytes != 16:
+            raise ValueError("uniforms must be 160 bytes and post uniforms 16 bytes")
+        self._check(lib().topo_update(self._h, width, height, _p(u), _p(pu)))
+        self.size = (width, height)
+
+    # render(...) + depth read-back with the reference's pad_256 row pitch    terrain_renderer.rs:365, render_engine.rs:219-249
+    def render(self, want_depth=True, padded_depth=False):
+        w, h = self.size
+        rgba = np.empty((h, w, 4), np.uint8)
+        if not want_depth:
+            self._check(lib().topo_render(self._h, _p(rgba), w * 4, None, 0))
+            return rgba, None
+        pitch = pad_256(4 * w) if padded_depth else 4 * w
+        depth = np.zeros((h, pitch // 4), np.float32)
+        self._check(lib().topo_render(self._h, _p(rgba), w * 4, _p(depth), pitch))
+        return rgba, (depth if padded_depth else depth[:, :w])
+
+    def recompute_normals(self):
+        self._check(lib().topo_recompute_normals(self._h))
+
+    def render_views_device(self, uniforms_list, width, height, rgba_ptr: int, rgba_view_stride: int, rgba_pitch: int,
+                            depth_ptr: int = 0, depth_view_stride: int = 0, depth_pitch: int = 0):
+        us = np.ascontiguousarray(np.stack([np.ascontiguousarray(u).view(np.uint8).reshape(160) for u in uniforms_list]))
+        self._check(lib().topo_render_views_device(self._h, len(uniforms_list), _p(us), width, height,
+                                                   C.c_void_p(rgba_ptr), rgba_view_stride, rgba_pitch,
+                                                   C.c_void_p(depth_ptr) if depth_ptr else None, depth_view_stride, depth_pitch))
+
+    def set_stream(self, hip_stream: int):
+        self._check(lib().topo_set_stream(self._h, C.c_void_p(hip_stream) if hip_stream else None))
+
+    def synchronize(self):
+        self._check(lib().topo_synchronize(self._h))
+
+    def set_normals_lds_rows(self, rows: int):
+        self._check(lib().topo_set_normals_lds_rows(self._h, rows))
+
+    def timings(self) -> dict:
+        out = np.zeros(TIMING_SLOTS, np.float32)
+        self._check(lib().topo_get_timings(self._h, _p(out)))
+        return {k: float(v) for k, v in zip(TIMING_NAMES, out) if k != "_"}
+
+    def counters(self) -> dict:
+        out = np.zeros(4, np.uint32)
+        self._check(lib().topo_get_counters(self._h, _p(out)))
+        return {"blocks_rastered": int(out[0]), "big_items": int(out[1]), "status": int(out[2]), "blocks_tested": int(out[3])}
+
+    def read_normals(self, lat_deg, lon_deg) -> np.ndarray:
+        w, h = self.tile_size
+        out = np.empty((h, w, 4), np.uint8)
+        self._check(lib().topo_read_normals(self._h, lat_deg, lon_deg, _p(out)))
+        return out
+
+    def probe_sincos(self, x: np.ndarray):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        s, c = np.empty_like(x), np.empty_like(x)
+        self._check(lib().topo_probe_sincos(self._h, _p(x), _p(s), _p(c), x.size))
+        return s, c

@@ -1,0 +1,531 @@
+// terrain_renderer.cpp -- host orchestration of the HIP terrain path (see terrain_renderer.hpp).
+#include "terrain_renderer.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+namespace topo {
+
+#define TOPO_HIP_TRY(expr)                                   \
+    do {                                                     \
+        hipError_t e_ = (expr);                              \
+        if (e_ != hipSuccess) return hip_fail(e_, #expr);    \
+    } while (0)
+
+int TerrainRenderer::fail(int code, const std::string& msg) {
+    err_ = msg;
+    return code;
+}
+
+int TerrainRenderer::hip_fail(hipError_t e, const char* what) {
+    err_ = std::string(what) + ": " + hipGetErrorString(e);
+    return TOPO_ERR_HIP;
+}
+
+int TerrainRenderer::bind_device() {
+    TOPO_HIP_TRY(hipSetDevice(device_));
+    return TOPO_OK;
+}
+
+// TerrainRenderer::new (terrain_renderer.rs:37-69): targets are allocated lazily at the first render.
+int TerrainRenderer::create(TerrainRenderer** out, int device, uint32_t w, uint32_t h, uint32_t format, std::string* err) {
+    *out = nullptr;
+    if (w == 0 || h == 0) { *err = "target size must be non-zero"; return TOPO_ERR_INVALID; }
+    if (format != TOPO_FORMAT_RGBA8_UNORM_SRGB) { *err = "only Rgba8UnormSrgb targets are supported"; return TOPO_ERR_UNSUPPORTED; }
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0) {
+        *err = std::string("no HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0") +
+               " (this library has no CPU fallback)";
+        return TOPO_ERR_HIP;
+    }
+    if (device < 0 || device >= count) { *err = "hip_device out of range"; return TOPO_ERR_INVALID; }
+    TerrainRenderer* r = new TerrainRenderer();
+    r->device_ = device;
+    r->W_ = w;
+    r->H_ = h;
+    e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipStreamCreate(&r->own_stream_);
+    for (int i = 0; i < 8 && e == hipSuccess; ++i) e = hipEventCreate(&r->ev_[i]);
+    if (e != hipSuccess) {
+        *err = std::string("HIP initialisation failed: ") + hipGetErrorString(e);
+        delete r;
+        return TOPO_ERR_HIP;
+    }
+    r->stream_ = r->own_stream_;
+    *out = r;
+    return TOPO_OK;
+}
+
+TerrainRenderer::~TerrainRenderer() {
+    (void)hipSetDevice(device_);
+    if (stream_) (void)hipStreamSynchronize(stream_);
+    for (auto& kv : tiles_) {
+        (void)hipFree(kv.second.d_heights);
+        (void)hipFree(kv.second.d_normals);
+        (void)hipFree(kv.second.d_minmax);
+    }
+    void* bufs[] = {d_tiles_, d_views_, d_vis_, d_work_, d_big_, d_counters_, d_out_rgba_, d_out_depth_};
+    for (void* p : bufs)
+        if (p) (void)hipFree(p);
+    for (auto& e : ev_)
+        if (e) (void)hipEventDestroy(e);
+    if (own_stream_) (void)hipStreamDestroy(own_stream_);
+}
+
+int TerrainRenderer::ensure(void** p, size_t* cap, size_t need) {
+    if (need <= *cap) return TOPO_OK;
+    if (*p) {
+        TOPO_HIP_TRY(hipStreamSynchronize(stream_));
+        TOPO_HIP_TRY(hipFree(*p));
+        *p = nullptr;
+        *cap = 0;
+    }
+    TOPO_HIP_TRY(hipMalloc(p, need));
+    *cap = need;
+    return TOPO_OK;
+}
+
+Tile* TerrainRenderer::find(int lat, int lon) {
+    auto it = tiles_.find(geo_key(lat, lon));
+    return it == tiles_.end() ? nullptr : &it->second;
+}
+
+// The compute-pass orchestration of add_terrain (terrain_renderer.rs:192-347): interior normals of the
+// new tile, then a seam pass for each loaded edge neighbour and a corner pass for each complete 2x2 block,
+// every one of them fed the NEW tile's uniforms (:275, :344).
+void TerrainRenderer::normals_for(Tile& nt, bool /*record*/) {
+    const int lat = nt.lat, lon = nt.lon;
+    launch_normals_interior(nt.dev, tile_w_, tile_h_, lds_rows_, stream_);
+    // only tiles inserted before `nt` count as loaded (all of them, except while replaying)
+    auto loaded = [&](int la, int lo) -> Tile* {
+        Tile* t = find(la, lo);
+        return (t && t != &nt && t->seq < nt.seq) ? t : nullptr;
+    };
+    Tile* left = loaded(lat, lon - 1);
+    Tile* right = loaded(lat, lon + 1);
+    Tile* top = loaded(lat + 1, lon);
+    Tile* bottom = loaded(lat - 1, lon);
+    Tile* top_left = loaded(lat + 1, lon - 1);
+    Tile* top_right = loaded(lat + 1, lon + 1);
+    Tile* bottom_left = loaded(lat - 1, lon - 1);
+    Tile* bottom_right = loaded(lat - 1, lon + 1);
+    if (left) launch_normals_edge(left->dev, nt.dev, nt.dev, tile_w_, tile_h_, false, stream_);
+    if (right) launch_normals_edge(nt.dev, right->dev, nt.dev, tile_w_, tile_h_, false, stream_);
+    if (top) launch_normals_edge(top->dev, nt.dev, nt.dev, tile_w_, tile_h_, true, stream_);
+    if (bottom) launch_normals_edge(nt.dev, bottom->dev, nt.dev, tile_w_, tile_h_, true, stream_);
+    if (top_left && top && left) launch_normals_corner(top_left->dev, top->dev, left->dev, nt.dev, nt.dev, tile_w_, tile_h_, stream_);
+    if (top && top_right && right) launch_normals_corner(top->dev, top_right->dev, nt.dev, right->dev, nt.dev, tile_w_, tile_h_, stream_);
+    if (left && bottom_left && bottom) launch_normals_corner(left->dev, nt.dev, bottom_left->dev, bottom->dev, nt.dev, tile_w_, tile_h_, stream_);
+    if (right && bottom && bottom_right) launch_normals_corner(nt.dev, right->dev, bottom->dev, bottom_right->dev, nt.dev, tile_w_, tile_h_, stream_);
+}
+
+int TerrainRenderer::add_terrain(int32_t lat, int32_t lon, const float* heights, bool on_device, uint32_t w, uint32_t h,
+                                 const float rp[2], const float mp[2], const float ps[2]) {
+    if (!heights || !rp || !mp || !ps) return fail(TOPO_ERR_INVALID, "null argument");
+    if (w < 3 || h < 3) return fail(TOPO_ERR_INVALID, "tile must be at least 3x3");
+    if (w > 32768 || h > 32768) return fail(TOPO_ERR_INVALID, "tile too large");
+    if (!tiles_.empty() && (w != tile_w_ || h != tile_h_))
+        return fail(TOPO_ERR_INVALID, "mixed tile sizes are rejected (the reference caches one mesh: render_buffer.rs:12-15)");
+    if (int rc = bind_device()) return rc;
+    const uint64_t tris = 2ull * (w - 1) * (h - 1);
+    const size_t n_after = tiles_.size() + (find(lat, lon) ? 0 : 1);
+    if (tris * n_after >= (1ull << 31) || n_after > 0xFFFFu) return fail(TOPO_ERR_CAPACITY, "draw-order id space exhausted");
+    tile_w_ = w;
+    tile_h_ = h;
+    const size_t texels = (size_t)w * h;
+    const uint32_t bxc = (w - 1 + kBCX - 1) / kBCX, byc = (h - 1 + kBCY - 1) / kBCY;
+    Tile t;
+    t.lat = lat;
+    t.lon = lon;
+    t.seq = next_seq_++;
+    TOPO_HIP_TRY(hipMalloc((void**)&t.d_heights, texels * 4));
+    hipError_t e = hipMalloc((void**)&t.d_normals, texels * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&t.d_minmax, (size_t)bxc * byc * 2 * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpyAsync(t.d_heights, heights, texels * 4, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream_);
+    if (e == hipSuccess) e = hipMemsetAsync(t.d_normals, 0, texels * 4, stream_);   // zero-initialised texture
+    if (e != hipSuccess) {
+        (void)hipFree(t.d_heights); (void)hipFree(t.d_normals); (void)hipFree(t.d_minmax);
+        return hip_fail(e, "tile allocation/upload");
+    }
+    // TerrainUniforms::new (render/data.rs:124-151)
+    t.dev.heights = t.d_heights;
+    t.dev.normals = t.d_normals;
+    t.dev.block_minmax = t.d_minmax;
+    t.dev.raster_x = rp[0]; t.dev.raster_y = rp[1];
+    t.dev.model_x = mp[0]; t.dev.model_y = mp[1];
+    t.dev.scale_x = ps[0]; t.dev.scale_y = ps[1];
+    terrain_rotation(mp[0], mp[1], t.dev.rot);
+    launch_block_minmax(t.d_heights, t.d_minmax, w, h, stream_);
+    // BTreeMap::insert replaces an existing entry; its GPU resources are dropped after the passes below
+    Tile old{};
+    bool had_old = false;
+    if (Tile* ex = find(lat, lon)) { old = *ex; had_old = true; tiles_.erase(geo_key(lat, lon)); }
+    Tile& nt = tiles_[geo_key(lat, lon)] = t;
+    normals_for(nt, true);
+    table_dirty_ = true;
+    if (!on_device) TOPO_HIP_TRY(hipStreamSynchronize(stream_));   // `heights` is only borrowed for the call
+    if (had_old) {
+        TOPO_HIP_TRY(hipStreamSynchronize(stream_));
+        (void)hipFree(old.d_heights); (void)hipFree(old.d_normals); (void)hipFree(old.d_minmax);
+    }
+    TOPO_HIP_TRY(hipGetLastError());
+    return TOPO_OK;
+}
+
+// unload_terrain (terrain_renderer.rs:361-363): neighbours keep whatever seam normals they have.
+int TerrainRenderer::unload_terrain(int32_t lat, int32_t lon) {
+    Tile* t = find(lat, lon);
+    if (!t) return TOPO_OK;   // BTreeMap::remove of a missing key is a no-op
+    if (int rc = bind_device()) return rc;
+    TOPO_HIP_TRY(hipStreamSynchronize(stream_));
+    (void)hipFree(t->d_heights); (void)hipFree(t->d_normals); (void)hipFree(t->d_minmax);
+    tiles_.erase(geo_key(lat, lon));
+    table_dirty_ = true;
+    return TOPO_OK;
+}
+
+int TerrainRenderer::recompute_normals() {
+    if (int rc = bind_device()) return rc;
+    std::vector<Tile*> order;
+    for (auto& kv : tiles_) order.push_back(&kv.second);
+    std::sort(order.begin(), order.end(), [](Tile* a, Tile* b) { return a->seq < b->seq; });
+    TOPO_HIP_TRY(hipEventRecord(ev_[6], stream_));
+    for (Tile* t : order) TOPO_HIP_TRY(hipMemsetAsync(t->d_normals, 0, (size_t)tile_w_ * tile_h_ * 4, stream_));
+    for (Tile* t : order) normals_for(*t, false);
+    TOPO_HIP_TRY(hipEventRecord(ev_[7], stream_));
+    load_timed_ = true;
+    TOPO_HIP_TRY(hipGetLastError());
+    return TOPO_OK;
+}
+
+// update (terrain_renderer.rs:151-171)
+int TerrainRenderer::update(uint32_t w, uint32_t h, const topo_uniforms* u, const topo_post_uniforms* pu) {
+    if (!u || !pu) return fail(TOPO_ERR_INVALID, "null argument");
+    if (w == 0 || h == 0) return fail(TOPO_ERR_INVALID, "target size must be non-zero");
+    if (pu->pixelize_n < 99.99999f) return fail(TOPO_ERR_UNSUPPORTED, "pixelize_n < 99.99999 is not supported (the reference always passes 100)");
+    W_ = w;
+    H_ = h;
+    uniforms_ = *u;
+    post_ = *pu;
+    have_uniforms_ = true;
+    return TOPO_OK;
+}
+
+int TerrainRenderer::upload_tile_table() {
+    if (!table_dirty_) return TOPO_OK;
+    std::vector<TileDev> table;
+    for (auto& kv : tiles_) table.push_back(kv.second.dev);   // std::map iterates in BTreeMap order
+    if (!table.empty()) {
+        if (int rc = ensure(&d_tiles_, &cap_tiles_, table.size() * sizeof(TileDev))) return rc;
+        TOPO_HIP_TRY(hipStreamSynchronize(stream_));
+        TOPO_HIP_TRY(hipMemcpy(d_tiles_, table.data(), table.size() * sizeof(TileDev), hipMemcpyHostToDevice));
+    }
+    table_dirty_ = false;
+    return TOPO_OK;
+}
+
+int TerrainRenderer::render_views_device(uint32_t n, const topo_uniforms* views, uint32_t w, uint32_t h, const OutputParams& out) {
+    if (n == 0 || !views || !out.rgba) return fail(TOPO_ERR_INVALID, "null/empty argument");
+    if (n > 0xFFFFu) return fail(TOPO_ERR_INVALID, "too many views");
+    if (w == 0 || h == 0 || w > 65536 || h > 65536) return fail(TOPO_ERR_INVALID, "bad target size");
+    if (int rc = bind_device()) return rc;
+    if (int rc = upload_tile_table()) return rc;
+    const uint32_t n_tiles = (uint32_t)tiles_.size();
+    const uint32_t bxc = n_tiles ? (tile_w_ - 1 + kBCX - 1) / kBCX : 0, byc = n_tiles ? (tile_h_ - 1 + kBCY - 1) / kBCY : 0;
+    const size_t pixels = (size_t)n * w * h;
+    const size_t work_cap = (size_t)n * n_tiles * bxc * byc;
+    const size_t big_cap = 1u << 22;
+    if (work_cap >= (1ull << 32)) return fail(TOPO_ERR_CAPACITY, "too many raster blocks in one submission");
+    if (int rc = ensure(&d_vis_, &cap_vis_, pixels * 8)) return rc;
+    if (int rc = ensure(&d_views_, &cap_views_, n * sizeof(ViewDev))) return rc;
+    if (int rc = ensure(&d_work_, &cap_work_, (work_cap ? work_cap : 1) * sizeof(WorkItem))) return rc;
+    if (int rc = ensure(&d_big_, &cap_big_, big_cap * sizeof(BigItem))) return rc;
+    if (!d_counters_) {
+        if (int rc = ensure(&d_counters_, &cap_counters_, 16 * sizeof(uint32_t))) return rc;
+        TOPO_HIP_TRY(hipMemsetAsync(d_counters_, 0, 16 * sizeof(uint32_t), stream_));
+    }
+    std::vector<ViewDev> vd(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        memcpy(vd[i].proj, views[i].camera_proj, sizeof vd[i].proj);
+        vd[i].cam_x = views[i].camera_pos[0];
+        vd[i].cam_y = views[i].camera_pos[1];
+        memcpy(vd[i].sun, views[i].sun_direction, sizeof vd[i].sun);
+        vd[i].view_mode = views[i].view_mode;
+    }
+    // pageable source: the runtime stages the bytes before hipMemcpyAsync returns
+    TOPO_HIP_TRY(hipMemcpyAsync(d_views_, vd.data(), n * sizeof(ViewDev), hipMemcpyHostToDevice, stream_));
+    TOPO_HIP_TRY(hipStreamSynchronize(stream_));
+
+    FrameParams p{};
+    p.tiles = (const TileDev*)d_tiles_;
+    p.views = (const ViewDev*)d_views_;
+    p.vis = (uint64_t*)d_vis_;
+    p.work = (WorkItem*)d_work_;
+    p.counters = (uint32_t*)d_counters_;
+    p.big = (BigItem*)d_big_;
+    p.work_cap = (uint32_t)work_cap;
+    p.big_cap = (uint32_t)big_cap;
+    p.n_views = n;
+    p.n_tiles = n_tiles;
+    p.W = (int32_t)w;
+    p.H = (int32_t)h;
+    p.tile_w = tile_w_;
+    p.tile_h = tile_h_;
+    p.bx_count = bxc;
+    p.by_count = byc;
+    p.tris_per_tile = n_tiles ? 2u * (tile_w_ - 1) * (tile_h_ - 1) : 1u;
+    last_blocks_tested_ = (uint32_t)work_cap;
+
+    TOPO_HIP_TRY(hipEventRecord(ev_[0], stream_));
+    launch_clear(p, stream_);
+    TOPO_HIP_TRY(hipEventRecord(ev_[1], stream_));
+    launch_cull(p, stream_);
+    TOPO_HIP_TRY(hipEventRecord(ev_[2], stream_));
+    launch_raster(p, stream_);
+    TOPO_HIP_TRY(hipEventRecord(ev_[3], stream_));
+    launch_raster_big(p, stream_);
+    TOPO_HIP_TRY(hipEventRecord(ev_[4], stream_));
+    launch_resolve(p, out, stream_);
+    TOPO_HIP_TRY(hipEventRecord(ev_[5], stream_));
+    frame_timed_ = true;
+    TOPO_HIP_TRY(hipGetLastError());
+    return TOPO_OK;
+}
+
+// render (terrain_renderer.rs:365-452) + depth copy (render_engine.rs:219-249), host outputs.
+int TerrainRenderer::render(uint8_t* rgba, size_t rgba_pitch, float* depth, size_t depth_pitch) {
+    if (!rgba) return fail(TOPO_ERR_INVALID, "rgba_out is null");
+    if (!have_uniforms_) return fail(TOPO_ERR_INVALID, "topo_update has not been called");
+    if (rgba_pitch < (size_t)W_ * 4 || (depth && depth_pitch < (size_t)W_ * 4)) return fail(TOPO_ERR_INVALID, "pitch smaller than a row");
+    if (int rc = bind_device()) return rc;
+    const size_t row = (size_t)W_ * 4;
+    if (int rc = ensure(&d_out_rgba_, &cap_out_rgba_, row * H_)) return rc;
+    if (depth)
+        if (int rc = ensure(&d_out_depth_, &cap_out_depth_, row * H_)) return rc;
+    OutputParams o{};
+    o.rgba = (uint8_t*)d_out_rgba_;
+    o.rgba_view_stride = row * H_;
+    o.rgba_pitch = row;
+    o.depth = depth ? (float*)d_out_depth_ : nullptr;
+    o.depth_view_stride = row * H_;
+    o.depth_pitch = row;
+    if (int rc = render_views_device(1, &uniforms_, W_, H_, o)) return rc;
+    TOPO_HIP_TRY(hipMemcpy2DAsync(rgba, rgba_pitch, d_out_rgba_, row, row, H_, hipMemcpyDeviceToHost, stream_));
+    if (depth) TOPO_HIP_TRY(hipMemcpy2DAsync(depth, depth_pitch, d_out_depth_, row, row, H_, hipMemcpyDeviceToHost, stream_));
+    TOPO_HIP_TRY(hipStreamSynchronize(stream_));
+    return TOPO_OK;
+}
+
+int TerrainRenderer::set_stream(hipStream_t s) {
+    if (int rc = bind_device()) return rc;
+    TOPO_HIP_TRY(hipStreamSynchronize(stream_));
+    stream_ = s ? s : own_stream_;
+    return TOPO_OK;
+}
+
+int TerrainRenderer::synchronize() {
+    if (int rc = bind_device()) return rc;
+    TOPO_HIP_TRY(hipStreamSynchronize(stream_));
+    return TOPO_OK;
+}
+
+int TerrainRenderer::set_normals_lds_rows(int rows) {
+    if (rows != 4 && rows != 8 && rows != 16 && rows != 32 && rows != 64) return fail(TOPO_ERR_INVALID, "lds rows must be 4, 8, 16, 32 or 64");
+    lds_rows_ = rows;
+    return TOPO_OK;
+}
+
+int TerrainRenderer::get_timings(float out[TOPO_TIMING_SLOTS]) {
+    for (int i = 0; i < TOPO_TIMING_SLOTS; ++i) out[i] = 0.0f;
+    if (int rc = bind_device()) return rc;
+    if (frame_timed_) {
+        TOPO_HIP_TRY(hipEventSynchronize(ev_[5]));
+        for (int i = 0; i < 5; ++i) TOPO_HIP_TRY(hipEventElapsedTime(&out[i], ev_[i], ev_[i + 1]));
+        TOPO_HIP_TRY(hipEventElapsedTime(&out[5], ev_[0], ev_[5]));
+    }
+    if (load_timed_) {
+        TOPO_HIP_TRY(hipEventSynchronize(ev_[7]));
+        TOPO_HIP_TRY(hipEventElapsedTime(&out[6], ev_[6], ev_[7]));
+    }
+    return TOPO_OK;
+}
+
+int TerrainRenderer::get_counters(uint32_t out[4]) {
+    out[0] = out[1] = out[2] = out[3] = 0;
+    if (!d_counters_) return TOPO_OK;
+    if (int rc = bind_device()) return rc;
+    TOPO_HIP_TRY(hipStreamSynchronize(stream_));
+    TOPO_HIP_TRY(hipMemcpy(out, d_counters_, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    out[3] = last_blocks_tested_;
+    return TOPO_OK;
+}
+
+int TerrainRenderer::read_normals(int32_t lat, int32_t lon, uint8_t* out) {
+    Tile* t = find(lat, lon);
+    if (!t) return fail(TOPO_ERR_NOT_FOUND, "no such tile");
+    if (int rc = bind_device()) return rc;
+    TOPO_HIP_TRY(hipStreamSynchronize(stream_));
+    TOPO_HIP_TRY(hipMemcpy(out, t->d_normals, (size_t)tile_w_ * tile_h_ * 4, hipMemcpyDeviceToHost));
+    return TOPO_OK;
+}
+
+int TerrainRenderer::probe_sincos(const float* x, float* s, float* c, size_t n) {
+    if (int rc = bind_device()) return rc;
+    float *dx = nullptr, *ds = nullptr, *dc = nullptr;
+    TOPO_HIP_TRY(hipMalloc((void**)&dx, n * 4));
+    TOPO_HIP_TRY(hipMalloc((void**)&ds, n * 4));
+    TOPO_HIP_TRY(hipMalloc((void**)&dc, n * 4));
+    TOPO_HIP_TRY(hipMemcpy(dx, x, n * 4, hipMemcpyHostToDevice));
+    launch_probe_sincos(dx, ds, dc, n, stream_);
+    TOPO_HIP_TRY(hipStreamSynchronize(stream_));
+    TOPO_HIP_TRY(hipMemcpy(s, ds, n * 4, hipMemcpyDeviceToHost));
+    TOPO_HIP_TRY(hipMemcpy(c, dc, n * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(dx); (void)hipFree(ds); (void)hipFree(dc);
+    return TOPO_OK;
+}
+
+// =========================================================================================================
+// Host-side CPU math of the reference (glam 0.31.0, Cargo.lock:1272-1273), restated in f32.
+// =========================================================================================================
+namespace {
+
+inline float rs_to_radians(float d) { return d * 0.017453292519943295f; }   // f32::to_radians
+
+struct V3 { float x, y, z; };
+inline float vdot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+inline V3 vcross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline V3 vnormalize(V3 v) {   // Vec3::normalize: self * length_recip()
+    const float r = 1.0f / sqrtf(vdot(v, v));
+    return {v.x * r, v.y * r, v.z * r};
+}
+
+// Mat3::from_euler(EulerRot::XYZEx, 0, b, c) = Rz(c) * Ry(b); with a = 0 every entry is one product.
+void euler_xyz_ex_a0(float b, float c, float m[9] /*column-major*/) {
+    const float si = sinf(0.0f), ci = cosf(0.0f);
+    const float sj = sinf(b), cj = cosf(b), sh = sinf(c), ch = cosf(c);
+    const float cc = ci * ch, cs = ci * sh, sc = si * ch, ss = si * sh;
+    m[0] = cj * ch;       m[1] = cj * sh;       m[2] = -sj;
+    m[3] = sj * sc - cs;  m[4] = sj * ss + cc;  m[5] = cj * si;
+    m[6] = sj * cc + ss;  m[7] = sj * cs - sc;  m[8] = cj * ci;
+}
+
+}  // namespace
+
+// TerrainUniforms::new's normal_to_world_rot (render/data.rs:125-133)
+void terrain_rotation(float model_lon_deg, float model_lat_deg, float rot[9]) {
+    euler_xyz_ex_a0(rs_to_radians(90.0f - model_lat_deg), rs_to_radians(model_lon_deg), rot);
+}
+
+// geometry::transform (render/geometry.rs:12-20)
+void geometry_transform(float h, float lon_deg, float lat_deg, float out[3]) {
+    const float r = kR0 + h;
+    const float lon = rs_to_radians(lon_deg), lat = rs_to_radians(lat_deg);
+    out[0] = r * cosf(lat) * cosf(lon);
+    out[1] = r * cosf(lat) * sinf(lon);
+    out[2] = r * sinf(lat);
+}
+
+// Uniforms::new (render/data.rs:44-58) over Camera::{up,direction,get_view,build_view_proj_matrix}
+// (data/camera.rs:97-128) and LightAngle::to_vec3 (:44-53).
+void camera_uniforms(const float eye_in[3], float yaw, float pitch, float fov_y, float width, float height,
+                     float sun_theta_deg, float sun_phi_deg, int32_t view_mode, topo_uniforms* out) {
+    memset(out, 0, sizeof *out);
+    const V3 eye = {eye_in[0], eye_in[1], eye_in[2]};
+    const V3 up = vnormalize(eye);
+    // Quat::from_rotation_arc(-Y, up)
+    const V3 from = {0.0f, -1.0f, 0.0f};
+    float qx, qy, qz, qw;
+    const float d = vdot(from, up);
+    const float one_minus_eps = 1.0f - 2.0f * 1.1920929e-7f;
+    if (d > one_minus_eps) {
+        qx = qy = qz = 0.0f; qw = 1.0f;
+    } else if (d < -one_minus_eps) {   // any_orthonormal_vector(from), half-turn
+        const float sign = copysignf(1.0f, from.z);
+        const float a = -1.0f / (sign + from.z);
+        const float b = from.x * from.y * a;
+        const V3 axis = {b, sign + from.y * from.y * a, -from.y};
+        const float s = sinf(3.14159265358979323846f * 0.5f), c = cosf(3.14159265358979323846f * 0.5f);
+        qx = axis.x * s; qy = axis.y * s; qz = axis.z * s; qw = c;
+    } else {
+        const V3 c = vcross(from, up);
+        const float w = 1.0f + d;
+        const float l2 = (c.x * c.x + c.z * c.z) + (c.y * c.y + w * w);   // SSE2 dot4 order
+        const float r = 1.0f / sqrtf(l2);
+        qx = c.x * r; qy = c.y * r; qz = c.z * r; qw = w * r;
+    }
+    // direction = rot * (cos yaw cos pitch, sin pitch, sin yaw cos pitch)   (Quat * Vec3)
+    const V3 v = {cosf(yaw) * cosf(pitch), sinf(pitch), sinf(yaw) * cosf(pitch)};
+    const V3 b = {qx, qy, qz};
+    const float b2 = vdot(b, b);
+    const float k0 = qw * qw - b2, k1 = vdot(v, b) * 2.0f, k2 = qw * 2.0f;
+    const V3 bxv = vcross(b, v);
+    const V3 f = {(v.x * k0 + b.x * k1) + bxv.x * k2, (v.y * k0 + b.y * k1) + bxv.y * k2, (v.z * k0 + b.z * k1) + bxv.z * k2};
+    // Mat4::look_to_rh(eye, f, up)
+    const V3 s = vnormalize(vcross(f, up));
+    const V3 u = vcross(s, f);
+    const float view[16] = {s.x, u.x, -f.x, 0.0f, s.y, u.y, -f.y, 0.0f, s.z, u.z, -f.z, 0.0f,
+                            -vdot(eye, s), -vdot(eye, u), vdot(eye, f), 1.0f};
+    // Mat4::perspective_rh(fov_y, aspect, NEAR, FAR)
+    const float aspect = width / height;
+    const float sf = sinf(0.5f * fov_y), cf = cosf(0.5f * fov_y);
+    const float hh = cf / sf, ww = hh / aspect, r = kFar / (kNear - kFar);
+    const float proj[16] = {ww, 0, 0, 0, 0, hh, 0, 0, 0, 0, r, -1.0f, 0, 0, r * kNear, 0};
+    for (int c = 0; c < 4; ++c)        // proj * view, column by column: ((c0*x + c1*y) + c2*z) + c3*w
+        for (int rr = 0; rr < 4; ++rr) {
+            float t = proj[rr] * view[c * 4 + 0];
+            t = t + proj[4 + rr] * view[c * 4 + 1];
+            t = t + proj[8 + rr] * view[c * 4 + 2];
+            t = t + proj[12 + rr] * view[c * 4 + 3];
+            out->camera_proj[c * 4 + rr] = t;
+        }
+    // normal_proj = view.inverse().transpose(): no shader reads it (render_shader.wgsl:5); filled with the
+    // rotation block of the view, which is what it equals for a rigid transform up to rounding.
+    for (int c = 0; c < 3; ++c)
+        for (int rr = 0; rr < 3; ++rr) out->normal_proj[c * 4 + rr] = view[c * 4 + rr];
+    out->normal_proj[15] = 1.0f;
+    out->camera_pos[0] = eye.x; out->camera_pos[1] = eye.y; out->camera_pos[2] = eye.z; out->camera_pos[3] = 0.0f;
+    float m3[9];
+    euler_xyz_ex_a0(rs_to_radians(90.0f - sun_phi_deg), rs_to_radians(sun_theta_deg), m3);
+    out->sun_direction[0] = m3[6]; out->sun_direction[1] = m3[7]; out->sun_direction[2] = m3[8];   // * Vec3::Z
+    out->view_mode = view_mode;
+}
+
+// Synthetic COP90-shaped heights: 5-octave value-noise fBm over global texel coordinates with an integer
+// hash (same definition as topo-renderer_amd/synth.py; f32 ops in the same order).
+namespace {
+inline float synth_hash(int64_t ix, int64_t iy, uint32_t seed) {
+    uint32_t h = ((uint32_t)ix * 0x9E3779B1u) ^ ((uint32_t)iy * 0x85EBCA77u) ^ (seed * 0xC2B2AE3Du);
+    h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
+    return (float)(h >> 8) * (1.0f / 16777216.0f);
+}
+}  // namespace
+
+void synth_tile(int32_t lat, int32_t lon, uint32_t w, uint32_t h, uint32_t seed, float* out) {
+    static const int wl[5] = {512, 256, 128, 64, 32};
+    static const float amp[5] = {1.0f, 0.5f, 0.25f, 0.125f, 0.0625f};
+    const float norm = (float)(3000.0 / 1.9375);
+    for (uint32_t y = 0; y < h; ++y) {
+        const int64_t gy = (int64_t)(89 - lat) * h + y;
+        for (uint32_t x = 0; x < w; ++x) {
+            const int64_t gx = ((int64_t)lon + 180) * w + x;
+            float acc = 0.0f;
+            for (int o = 0; o < 5; ++o) {
+                const int64_t cx = gx / wl[o], cy = gy / wl[o];
+                const float fx = (float)(gx % wl[o]) / (float)wl[o], fy = (float)(gy % wl[o]) / (float)wl[o];
+                const float ux = fx * fx * (3.0f - 2.0f * fx), uy = fy * fy * (3.0f - 2.0f * fy);
+                const uint32_t s = seed + (uint32_t)o;
+                const float v00 = synth_hash(cx, cy, s), v10 = synth_hash(cx + 1, cy, s);
+                const float v01 = synth_hash(cx, cy + 1, s), v11 = synth_hash(cx + 1, cy + 1, s);
+                const float a = v00 + ux * (v10 - v00), b = v01 + ux * (v11 - v01);
+                const float v = a + uy * (b - a);
+                acc = acc + amp[o] * v;
+            }
+            out[(size_t)y * w + x] = acc * norm;
+        }
+    }
+}
+
+}  // namespace topo

@@ -1,0 +1,106 @@
+// terrain_renderer.hpp -- host side of the MI355X terrain path: a C++ mirror of the reference's
+// `TerrainRenderer` (topo-renderer/src/render/terrain_renderer.rs) with the same five methods
+// (new / update / add_terrain / unload_terrain / render).  The reference's host code is Rust; no Rust
+// toolchain exists in this image, so the host side above the C ABI is C++ (include/topo_hip.h wraps this
+// class one-to-one; INTEGRATION.md has the Rust shim).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <map>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../include/topo_hip.h"
+#include "topo_kernels.h"
+
+namespace topo {
+
+// BTreeMap<GeoLocation, _> key: Ord over {latitude{degree,direction S<N}, longitude{degree,direction W<E}}
+// (topo-common/src/lib.rs:7-38); GeoLocation::from_coord maps sign > 0 to N/E, else S/W (:102-121).
+using GeoKey = std::tuple<int, int, int, int>;
+inline GeoKey geo_key(int lat, int lon) {
+    return GeoKey(lat < 0 ? -lat : lat, lat > 0 ? 1 : 0, lon < 0 ? -lon : lon, lon > 0 ? 1 : 0);
+}
+
+struct Tile {          // RenderBuffer (render_buffer.rs:23-31) minus the wgpu plumbing
+    int lat = 0, lon = 0;
+    uint64_t seq = 0;  // insertion order (for topo_recompute_normals)
+    float* d_heights = nullptr;
+    uint32_t* d_normals = nullptr;
+    float* d_minmax = nullptr;
+    TileDev dev{};
+};
+
+class TerrainRenderer {
+   public:
+    static int create(TerrainRenderer** out, int device, uint32_t w, uint32_t h, uint32_t format, std::string* err);
+    ~TerrainRenderer();
+
+    int add_terrain(int32_t lat, int32_t lon, const float* heights, bool heights_on_device, uint32_t w, uint32_t h,
+                    const float rp[2], const float mp[2], const float ps[2]);
+    int unload_terrain(int32_t lat, int32_t lon);
+    int update(uint32_t w, uint32_t h, const topo_uniforms* u, const topo_post_uniforms* pu);
+    int render(uint8_t* rgba, size_t rgba_pitch, float* depth, size_t depth_pitch);
+    int render_views_device(uint32_t n, const topo_uniforms* views, uint32_t w, uint32_t h, const OutputParams& out);
+    int recompute_normals();
+
+    int set_stream(hipStream_t s);
+    int synchronize();
+    int set_normals_lds_rows(int rows);
+    int get_timings(float out[TOPO_TIMING_SLOTS]);
+    int get_counters(uint32_t out[4]);
+    int read_normals(int32_t lat, int32_t lon, uint8_t* out);
+    int probe_sincos(const float* x, float* s, float* c, size_t n);
+
+    const char* last_error() const { return err_.c_str(); }
+
+   private:
+    TerrainRenderer() = default;
+    int fail(int code, const std::string& msg);
+    int hip_fail(hipError_t e, const char* what);
+    int bind_device();
+    int ensure(void** p, size_t* cap, size_t need);
+    void normals_for(Tile& nt, bool record);   // the K1-K3 orchestration of add_terrain
+    Tile* find(int lat, int lon);
+    int upload_tile_table();
+
+    int device_ = 0;
+    uint32_t W_ = 0, H_ = 0;
+    uint32_t tile_w_ = 0, tile_h_ = 0;
+    topo_uniforms uniforms_{};
+    topo_post_uniforms post_{};
+    bool have_uniforms_ = false;
+    std::map<GeoKey, Tile> tiles_;
+    uint64_t next_seq_ = 1;
+    bool table_dirty_ = true;
+    int lds_rows_ = 16;
+
+    hipStream_t own_stream_ = nullptr, stream_ = nullptr;
+    hipEvent_t ev_[8] = {};
+    bool frame_timed_ = false, load_timed_ = false;
+
+    // grow-only device buffers
+    void* d_tiles_ = nullptr;    size_t cap_tiles_ = 0;
+    void* d_views_ = nullptr;    size_t cap_views_ = 0;
+    void* d_vis_ = nullptr;      size_t cap_vis_ = 0;
+    void* d_work_ = nullptr;     size_t cap_work_ = 0;
+    void* d_big_ = nullptr;      size_t cap_big_ = 0;
+    void* d_counters_ = nullptr; size_t cap_counters_ = 0;
+    void* d_out_rgba_ = nullptr; size_t cap_out_rgba_ = 0;
+    void* d_out_depth_ = nullptr; size_t cap_out_depth_ = 0;
+    uint32_t last_blocks_tested_ = 0;
+
+    std::string err_;
+};
+
+// host-side restatements of the reference's CPU math (glam 0.31)
+void camera_uniforms(const float eye[3], float yaw, float pitch, float fov_y, float width, float height,
+                     float sun_theta_deg, float sun_phi_deg, int32_t view_mode, topo_uniforms* out);
+void geometry_transform(float h, float lon_deg, float lat_deg, float out[3]);
+void terrain_rotation(float model_lon_deg, float model_lat_deg, float rot3x3_colmajor[9]);
+void synth_tile(int32_t lat, int32_t lon, uint32_t w, uint32_t h, uint32_t seed, float* out);
+
+}  // namespace topo

@@ -1,0 +1,167 @@
+// topo_capi.cpp -- the extern "C" boundary (include/topo_hip.h) over topo::TerrainRenderer.
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "terrain_renderer.hpp"
+
+struct topo_ctx {
+    topo::TerrainRenderer* r = nullptr;
+};
+
+namespace {
+thread_local std::string g_create_error;   // topo_last_error(NULL) reports why topo_create failed
+}
+
+#define TOPO_GUARD(ctx)                       \
+    if (!(ctx) || !(ctx)->r) return TOPO_ERR_INVALID
+
+extern "C" {
+
+int topo_create(topo_ctx** out, int hip_device, uint32_t width, uint32_t height, uint32_t color_format) {
+    if (!out) return TOPO_ERR_INVALID;
+    *out = nullptr;
+    topo::TerrainRenderer* r = nullptr;
+    int rc;
+    try {
+        rc = topo::TerrainRenderer::create(&r, hip_device, width, height, color_format, &g_create_error);
+    } catch (const std::exception& e) {
+        g_create_error = e.what();
+        return TOPO_ERR_HIP;
+    }
+    if (rc != TOPO_OK) return rc;
+    topo_ctx* c = new (std::nothrow) topo_ctx();
+    if (!c) { delete r; return TOPO_ERR_HIP; }
+    c->r = r;
+    *out = c;
+    return TOPO_OK;
+}
+
+void topo_destroy(topo_ctx* ctx) {
+    if (!ctx) return;
+    delete ctx->r;
+    delete ctx;
+}
+
+const char* topo_last_error(topo_ctx* ctx) {
+    if (!ctx || !ctx->r) return g_create_error.c_str();
+    return ctx->r->last_error();
+}
+
+#define TOPO_CALL(expr)                                         \
+    try {                                                       \
+        return (expr);                                          \
+    } catch (const std::exception&) {                           \
+        return TOPO_ERR_HIP;                                    \
+    }
+
+int topo_add_terrain(topo_ctx* ctx, int32_t lat, int32_t lon, const float* heights, uint32_t w, uint32_t h,
+                     const float rp[2], const float mp[2], const float ps[2]) {
+    TOPO_GUARD(ctx);
+    TOPO_CALL(ctx->r->add_terrain(lat, lon, heights, false, w, h, rp, mp, ps));
+}
+
+int topo_add_terrain_device(topo_ctx* ctx, int32_t lat, int32_t lon, const float* heights_dev, uint32_t w, uint32_t h,
+                            const float rp[2], const float mp[2], const float ps[2]) {
+    TOPO_GUARD(ctx);
+    TOPO_CALL(ctx->r->add_terrain(lat, lon, heights_dev, true, w, h, rp, mp, ps));
+}
+
+int topo_unload_terrain(topo_ctx* ctx, int32_t lat, int32_t lon) {
+    TOPO_GUARD(ctx);
+    TOPO_CALL(ctx->r->unload_terrain(lat, lon));
+}
+
+int topo_update(topo_ctx* ctx, uint32_t w, uint32_t h, const topo_uniforms* u, const topo_post_uniforms* pu) {
+    TOPO_GUARD(ctx);
+    TOPO_CALL(ctx->r->update(w, h, u, pu));
+}
+
+int topo_render(topo_ctx* ctx, uint8_t* rgba, size_t rgba_pitch, float* depth, size_t depth_pitch) {
+    TOPO_GUARD(ctx);
+    TOPO_CALL(ctx->r->render(rgba, rgba_pitch, depth, depth_pitch));
+}
+
+int topo_recompute_normals(topo_ctx* ctx) {
+    TOPO_GUARD(ctx);
+    TOPO_CALL(ctx->r->recompute_normals());
+}
+
+int topo_render_views_device(topo_ctx* ctx, uint32_t n_views, const topo_uniforms* views, uint32_t width, uint32_t height,
+                             uint8_t* rgba_dev, size_t rgba_view_stride, size_t rgba_pitch, float* depth_dev,
+                             size_t depth_view_stride, size_t depth_pitch) {
+    TOPO_GUARD(ctx);
+    topo::OutputParams o{};
+    o.rgba = rgba_dev;
+    o.rgba_view_stride = rgba_view_stride;
+    o.rgba_pitch = rgba_pitch;
+    o.depth = depth_dev;
+    o.depth_view_stride = depth_view_stride;
+    o.depth_pitch = depth_pitch;
+    TOPO_CALL(ctx->r->render_views_device(n_views, views, width, height, o));
+}
+
+int topo_set_stream(topo_ctx* ctx, void* hip_stream) {
+    TOPO_GUARD(ctx);
+    TOPO_CALL(ctx->r->set_stream((hipStream_t)hip_stream));
+}
+
+int topo_synchronize(topo_ctx* ctx) {
+    TOPO_GUARD(ctx);
+    TOPO_CALL(ctx->r->synchronize());
+}
+
+int topo_set_normals_lds_rows(topo_ctx* ctx, int rows) {
+    TOPO_GUARD(ctx);
+    return ctx->r->set_normals_lds_rows(rows);
+}
+
+int topo_get_timings(topo_ctx* ctx, float out_ms[TOPO_TIMING_SLOTS]) {
+    TOPO_GUARD(ctx);
+    TOPO_CALL(ctx->r->get_timings(out_ms));
+}
+
+int topo_get_counters(topo_ctx* ctx, uint32_t out[4]) {
+    TOPO_GUARD(ctx);
+    TOPO_CALL(ctx->r->get_counters(out));
+}
+
+int topo_read_normals(topo_ctx* ctx, int32_t lat, int32_t lon, uint8_t* out) {
+    TOPO_GUARD(ctx);
+    TOPO_CALL(ctx->r->read_normals(lat, lon, out));
+}
+
+int topo_probe_sincos(topo_ctx* ctx, const float* x, float* s, float* c, size_t n) {
+    TOPO_GUARD(ctx);
+    TOPO_CALL(ctx->r->probe_sincos(x, s, c, n));
+}
+
+void topo_camera_uniforms(const float eye[3], float yaw, float pitch, float fov_y, float width, float height,
+                          float sun_theta_deg, float sun_phi_deg, int32_t view_mode, topo_uniforms* out) {
+    topo::camera_uniforms(eye, yaw, pitch, fov_y, width, height, sun_theta_deg, sun_phi_deg, view_mode, out);
+}
+
+void topo_terrain_uniforms(const float rp[2], const float mp[2], const float ps[2], uint32_t w, uint32_t h, float out[24]) {
+    memset(out, 0, 24 * sizeof(float));
+    out[0] = rp[0]; out[1] = rp[1]; out[2] = mp[0]; out[3] = mp[1]; out[4] = ps[0]; out[5] = ps[1];
+    out[6] = (float)w; out[7] = (float)h;
+    float rot[9];
+    topo::terrain_rotation(mp[0], mp[1], rot);
+    for (int c = 0; c < 3; ++c)
+        for (int r = 0; r < 3; ++r) out[8 + c * 4 + r] = rot[c * 3 + r];   // Mat4::from_mat3
+    out[8 + 15] = 1.0f;
+}
+
+void topo_geometry_transform(float h, float lon_deg, float lat_deg, float out[3]) {
+    topo::geometry_transform(h, lon_deg, lat_deg, out);
+}
+
+float topo_dist_from_depth(float depth) { return topo::kFar * topo::kNear / (topo::kFar - depth * (topo::kFar - topo::kNear)); }
+
+uint32_t topo_pad_256(uint32_t size) { return ((size - 1) / 256 + 1) * 256; }
+
+void topo_synth_tile(int32_t lat, int32_t lon, uint32_t w, uint32_t h, uint32_t seed, float* out) {
+    topo::synth_tile(lat, lon, w, h, seed, out);
+}
+
+}  // extern "C"

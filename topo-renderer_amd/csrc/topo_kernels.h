@@ -1,0 +1,69 @@
+// topo_kernels.h -- launch interface of the gfx950 kernels (topo_kernels.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "topo_pipeline.h"
+
+namespace topo {
+
+// Raster work decomposition: a tile's (w-1) x (h-1) cell grid is cut into blocks of kBCX x kBCY cells
+// ((kBCX+1) x (kBCY+1) vertices staged in LDS by one 256-thread workgroup).  1199 = 19*60+59 = 79*15+14,
+// so a 1200x1200 COP90 tile gives 20 x 80 blocks with no sliver blocks.
+constexpr uint32_t kBCX = 60, kBCY = 15;
+constexpr uint32_t kVX = kBCX + 1, kVY = kBCY + 1;
+
+struct WorkItem {          // one (view, tile, block) that survived the frustum cull
+    uint32_t view_rank;    // view << 16 | tile rank (draw order)
+    uint32_t block;        // by * bx_count + bx
+};
+
+struct BigItem {           // a triangle too large for the in-lane loop, restricted to one 64x64 px region
+    uint32_t view;
+    uint32_t id;           // draw << 1 | fan   (kNoTri = empty slot)
+    uint32_t rx, ry;       // region index (64 px units)
+};
+
+struct FrameParams {
+    const TileDev* tiles;      // n_tiles entries in draw order (BTreeMap order, terrain_renderer.rs:407)
+    const ViewDev* views;      // n_views
+    uint64_t* vis;             // n_views * W * H visibility keys: depth bits << 32 | id
+    WorkItem* work;
+    uint32_t* counters;        // [0] work count, [1] big count, [2] status bits
+    BigItem* big;
+    uint32_t work_cap, big_cap;
+    uint32_t n_views, n_tiles;
+    int32_t W, H;
+    uint32_t tile_w, tile_h;
+    uint32_t bx_count, by_count;
+    uint32_t tris_per_tile;
+};
+
+struct OutputParams {
+    uint8_t* rgba;             // device pointer
+    size_t rgba_view_stride, rgba_pitch;   // bytes
+    float* depth;              // device pointer or null
+    size_t depth_view_stride, depth_pitch; // bytes
+};
+
+constexpr uint32_t kStatusBigOverflow = 1u;
+
+// load phase (add_terrain)
+void launch_block_minmax(const float* heights, float* minmax, uint32_t w, uint32_t h, hipStream_t s);
+void launch_normals_interior(const TileDev& t, uint32_t w, uint32_t h, int lds_rows, hipStream_t s);
+void launch_normals_edge(const TileDev& lt, const TileDev& rb, const TileDev& uni, uint32_t w, uint32_t h,
+                         bool top_bottom, hipStream_t s);
+void launch_normals_corner(const TileDev& lt, const TileDev& rt, const TileDev& lb, const TileDev& rb,
+                           const TileDev& uni, uint32_t w, uint32_t h, hipStream_t s);
+
+// frame phase (render)
+void launch_clear(const FrameParams& p, hipStream_t s);
+void launch_cull(const FrameParams& p, hipStream_t s);
+void launch_raster(const FrameParams& p, hipStream_t s);
+void launch_raster_big(const FrameParams& p, hipStream_t s);
+void launch_resolve(const FrameParams& p, const OutputParams& o, hipStream_t s);
+
+// unit-test probes
+void launch_probe_sincos(const float* x, float* s, float* c, size_t n, hipStream_t st);
+
+}  // namespace topo

@@ -1,0 +1,483 @@
+// topo_kernels.hip -- gfx950 (CDNA4, wave64) kernels of the terrain path.
+//
+//   load phase   k_block_minmax, k_normals_interior<ROWS>, k_normals_edge, k_normals_corner
+//                (compute_normals*.wgsl; once per add_terrain)
+//   frame phase  k_clear -> k_cull -> k_raster -> k_raster_big -> k_resolve
+//                (render_shader.wgsl vs_main + fixed-function raster/depth, fs_main, postprocessing_shader.wgsl)
+//
+// The frame is a visibility-buffer renderer: every surviving fragment does a 64-bit atomic min of
+// (depth bits << 32 | draw-order id) -- the minimum reproduces CompareFunction::Less *and* the API-order
+// tie-break of the reference's in-order draws -- and one resolve pass shades the winner of each pixel and
+// applies the contour post pass.  HBM-bound integer/float work; no MFMA (there is no contraction).
+//
+// Compiled with -ffp-contract=off: results must match the arithmetic spec bit for bit.
+#include "topo_kernels.h"
+
+namespace topo {
+
+namespace {
+
+__device__ __forceinline__ void vis_min(uint64_t* p, uint64_t key) {
+    // stale reads only ever see an older (larger) key, so the pre-test is conservative
+    const uint64_t cur = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (key < cur) atomicMin(reinterpret_cast<unsigned long long*>(p), (unsigned long long)key);
+}
+
+// ======================================================================================================
+// load phase
+// ======================================================================================================
+
+// min/max height of the (kVX x kVY) vertices of every raster block; one wave per block.
+__global__ __launch_bounds__(64) void k_block_minmax(const float* __restrict__ heights, float* __restrict__ minmax,
+                                                     uint32_t w, uint32_t h, uint32_t bx_count) {
+    const uint32_t blk = blockIdx.x, bx = blk % bx_count, by = blk / bx_count;
+    const uint32_t x = bx * kBCX + threadIdx.x;
+    float mn = INFINITY, mx = -INFINITY;
+    if (threadIdx.x < kVX && x < w) {
+        for (uint32_t r = 0; r < kVY; ++r) {
+            const uint32_t y = by * kBCY + r;
+            if (y >= h) break;
+            const float v = heights[(size_t)y * w + x];
+            mn = fminf(mn, v);
+            mx = fmaxf(mx, v);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        mn = fminf(mn, __shfl_xor(mn, off));
+        mx = fmaxf(mx, __shfl_xor(mx, off));
+    }
+    if (threadIdx.x == 0) {
+        minmax[2 * blk] = mn;
+        minmax[2 * blk + 1] = mx;
+    }
+}
+
+// Interior normals (compute_normals_shader.wgsl:22-51).  64 x ROWS output texels per 256-thread
+// workgroup; the (ROWS+2) x 66 height tile is staged in LDS with coalesced row loads, each texel's four
+// taps then come from LDS.  ROWS is the LDS tile-size knob swept in the benches.
+template <int ROWS>
+__global__ __launch_bounds__(256) void k_normals_interior(const float* __restrict__ heights, uint32_t* __restrict__ normals,
+                                                          int W, int H, float raster_y, float model_y, float scale_x,
+                                                          float scale_y) {
+    __shared__ float tile[ROWS + 2][66];
+    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * ROWS;
+    for (int idx = threadIdx.x; idx < (ROWS + 2) * 66; idx += 256) {
+        const int ly = idx / 66, lx = idx - ly * 66;
+        const int gx = x0 + lx - 1, gy = y0 + ly - 1;
+        float v = 0.0f;
+        if (gx >= 0 && gx < W && gy >= 0 && gy < H) v = heights[(size_t)gy * W + gx];
+        tile[ly][lx] = v;
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int gx = x0 + tx;
+    const float xs = deg2rad(scale_x) * kR0;
+    const float ys0 = deg2rad(scale_y) * kR0;
+#pragma unroll
+    for (int r = ty; r < ROWS; r += 4) {
+        const int gy = y0 + r;
+        if (gx < 1 || gy < 1 || gx >= W - 1 || gy >= H - 1) continue;
+        const float latitude = ((float)gy - raster_y) * -scale_y + model_y;
+        const float ys = ys0 * cos_f(deg2rad(latitude));
+        const uint32_t texel = normal_texel(xs, ys, tile[r][tx + 1], tile[r + 1][tx], tile[r + 1][tx + 2], tile[r + 2][tx + 1]);
+        normals[(size_t)gy * W + gx] = texel;
+    }
+}
+
+// Seam normals (compute_normals_edge_shader.wgsl:25-105).  `u*` = uniforms of the newly added tile.
+__global__ __launch_bounds__(64) void k_normals_edge(const float* __restrict__ h_lt, const float* __restrict__ h_rb,
+                                                     uint32_t* __restrict__ n_lt, uint32_t* __restrict__ n_rb, int W, int H,
+                                                     float raster_y, float model_y, float scale_x, float scale_y,
+                                                     int top_bottom) {
+    const int id = blockIdx.x * 64 + threadIdx.x;
+    if (id < 1 || id >= W - 1) return;
+    const float xs = deg2rad(fabsf(scale_x)) * kR0;
+    const float ys0 = deg2rad(fabsf(scale_y)) * kR0;
+    if (!top_bottom) {
+        if (id >= H - 1) return;   // the guard uses dimensions.x although id runs along y; see DESIGN.md
+        const float latitude = ((float)id - raster_y) * -scale_y + model_y;
+        const float ys = ys0 * cos_f(deg2rad(latitude));
+        const int lx = W - 1, ly = id, rx = 0, ry = id;
+        const float hT = h_lt[(size_t)(ly - 1) * W + lx], hL = h_lt[(size_t)ly * W + lx - 1];
+        const float hR = h_rb[(size_t)ry * W + rx + 1], hB = h_lt[(size_t)(ly + 1) * W + lx];
+        const uint32_t texel = normal_texel(xs, ys, hT, hL, hR, hB);
+        n_lt[(size_t)ly * W + lx] = texel;
+        n_rb[(size_t)ry * W + rx] = texel;
+    } else {
+        const float latitude = ((float)(H - 1) - raster_y) * -scale_y + model_y;
+        const float ys = ys0 * cos_f(deg2rad(latitude));
+        const int tx = id, ty = H - 1, bx = id, by = 0;
+        const float hT = h_lt[(size_t)(ty - 1) * W + tx], hL = h_lt[(size_t)ty * W + tx - 1];
+        const float hR = h_lt[(size_t)ty * W + tx + 1], hB = h_rb[(size_t)(by + 1) * W + bx];
+        const uint32_t texel = normal_texel(xs, ys, hT, hL, hR, hB);
+        n_lt[(size_t)ty * W + tx] = texel;
+        n_rb[(size_t)by * W + bx] = texel;
+    }
+}
+
+// Shared corner of a 2x2 block (compute_normals_corner_shader.wgsl:29-63); `top` comes from the
+// bottom-right tile at (0, H-2) exactly as the shader reads it (:49).
+__global__ void k_normals_corner(const float* __restrict__ h_lt, const float* __restrict__ h_rt, const float* __restrict__ h_lb,
+                                 const float* __restrict__ h_rb, uint32_t* __restrict__ n_lt, uint32_t* __restrict__ n_rt,
+                                 uint32_t* __restrict__ n_lb, uint32_t* __restrict__ n_rb, int W, int H, float raster_y,
+                                 float model_y, float scale_x, float scale_y) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float latitude = ((float)(H - 1) - raster_y) * -scale_y + model_y;
+    const float xs = deg2rad(fabsf(scale_x)) * kR0;
+    const float ys = deg2rad(fabsf(scale_y)) * kR0 * cos_f(deg2rad(latitude));
+    const float hT = h_rb[(size_t)(H - 2) * W + 0];
+    const float hL = h_lt[(size_t)(H - 1) * W + (W - 2)];
+    const float hR = h_rt[(size_t)(H - 1) * W + 1];
+    const float hB = h_lb[(size_t)1 * W + (W - 1)];
+    const uint32_t texel = normal_texel(xs, ys, hT, hL, hR, hB);
+    n_lt[(size_t)(H - 1) * W + (W - 1)] = texel;
+    n_rt[(size_t)(H - 1) * W + 0] = texel;
+    n_lb[(size_t)0 * W + (W - 1)] = texel;
+    n_rb[0] = texel;
+}
+
+// ======================================================================================================
+// frame phase
+// ======================================================================================================
+
+__global__ __launch_bounds__(256) void k_clear(uint64_t* __restrict__ vis, size_t n, uint32_t* __restrict__ counters) {
+    if (blockIdx.x == 0 && threadIdx.x < 2) counters[threadIdx.x] = 0;   // work count, big count (status is sticky)
+    const size_t stride = (size_t)gridDim.x * blockDim.x * 2;
+    for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 2; i < n; i += stride) {
+        if (i + 1 < n) {
+            *reinterpret_cast<ulonglong2*>(vis + i) = make_ulonglong2(kVisClear, kVisClear);
+        } else {
+            vis[i] = kVisClear;
+        }
+    }
+}
+
+// Conservative frustum test of one raster block against one view, in f64.  A block is kept unless its
+// bounding sphere (inflated by 64 m for the f32 noise of the real vertex path) lies wholly outside one of
+// the six clip planes of camera_proj.  Culling is result-neutral: culled blocks cannot produce fragments.
+__device__ void world_f64(const TileDev& t, double vx, double vy, double height, double out[3]) {
+    const double lon = ((vx - (double)t.raster_x) * (double)t.scale_x + (double)t.model_x) * 0.017453292519943295;
+    const double lat = ((vy - (double)t.raster_y) * -(double)t.scale_y + (double)t.model_y) * 0.017453292519943295;
+    const double R = (double)kR0 + height;
+    out[0] = R * cos(lat) * cos(lon);
+    out[1] = R * cos(lat) * sin(lon);
+    out[2] = R * sin(lat);
+}
+
+__global__ __launch_bounds__(256) void k_cull(FrameParams P) {
+    const uint32_t blocks_per_tile = P.bx_count * P.by_count;
+    const size_t total = (size_t)P.n_views * P.n_tiles * blocks_per_tile;
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const uint32_t blk = (uint32_t)(gid % blocks_per_tile);
+    const uint32_t rank = (uint32_t)((gid / blocks_per_tile) % P.n_tiles);
+    const uint32_t view = (uint32_t)(gid / ((size_t)blocks_per_tile * P.n_tiles));
+    const TileDev& t = P.tiles[rank];
+    const uint32_t bx = blk % P.bx_count, by = blk / P.bx_count;
+    const double x0 = (double)(bx * kBCX), y0 = (double)(by * kBCY);
+    double x1 = x0 + (double)kBCX, y1 = y0 + (double)kBCY;
+    if (x1 > (double)(P.tile_w - 1)) x1 = (double)(P.tile_w - 1);
+    if (y1 > (double)(P.tile_h - 1)) y1 = (double)(P.tile_h - 1);
+    const double hmin = (double)t.block_minmax[2 * blk], hmax = (double)t.block_minmax[2 * blk + 1];
+    const double hmid = 0.5 * (hmin + hmax);
+    double c[3], q[3];
+    world_f64(t, 0.5 * (x0 + x1), 0.5 * (y0 + y1), hmid, c);
+    double r2 = 0.0;
+    const double cxs[4] = {x0, x1, x0, x1}, cys[4] = {y0, y0, y1, y1};
+    for (int k = 0; k < 4; ++k) {
+        world_f64(t, cxs[k], cys[k], hmid, q);
+        const double d2 = (q[0] - c[0]) * (q[0] - c[0]) + (q[1] - c[1]) * (q[1] - c[1]) + (q[2] - c[2]) * (q[2] - c[2]);
+        r2 = d2 > r2 ? d2 : r2;
+    }
+    // corners bound the patch up to its sagitta (< 1 m for a 6 km block); + half the height range + margin
+    const double radius = sqrt(r2) + 0.5 * (hmax - hmin) + 8.0 + 64.0;
+    const float* m = P.views[view].proj;
+    bool keep = true;
+    for (int pl = 0; pl < 6 && keep; ++pl) {
+        double a, b, cc, d;
+        const int row = pl >> 1;            // 0: x, 1: y, 2: z
+        const double sgn = (pl & 1) ? -1.0 : 1.0;
+        if (pl == 4) {                      // near: z_clip >= 0
+            a = m[2]; b = m[6]; cc = m[10]; d = m[14];
+        } else {                            // w +- row
+            a = (double)m[3] + sgn * (double)m[row];
+            b = (double)m[7] + sgn * (double)m[4 + row];
+            cc = (double)m[11] + sgn * (double)m[8 + row];
+            d = (double)m[15] + sgn * (double)m[12 + row];
+        }
+        const double dist = a * c[0] + b * c[1] + cc * c[2] + d;
+        const double nrm = sqrt(a * a + b * b + cc * cc);
+        if (dist < -radius * nrm) keep = false;
+    }
+    if (!(hmin <= hmax)) keep = true;       // NaN heights: let the raster path deal with it
+    if (keep) {
+        const uint32_t slot = atomicAdd(&P.counters[0], 1u);
+        if (slot < P.work_cap) P.work[slot] = WorkItem{(view << 16) | rank, blk};
+    }
+}
+
+// ---- raster ------------------------------------------------------------------------------------------
+
+// Pixel loop shared by the in-lane path and the big-triangle path.
+__device__ __forceinline__ void raster_box(const TriSetup& ts, uint64_t* __restrict__ vis, int32_t W, uint32_t id,
+                                           int32_t px0, int32_t px1, int32_t py0, int32_t py1) {
+    for (int32_t py = py0; py <= py1; ++py)
+        for (int32_t px = px0; px <= px1; ++px) {
+            float z, b[3];
+            if (triangle_pixel(ts, px, py, z, b)) vis_min(vis + (size_t)py * W + px, vis_key(z, id));
+        }
+}
+
+// A set-up triangle: rasterise in-lane when its pixel box is tiny, otherwise hand one BigItem per
+// overlapped 64x64 region to k_raster_big (falling back to the in-lane loop if the queue is full).
+__device__ void emit_triangle(const FrameParams& P, const TriSetup& ts, uint32_t view, uint32_t id) {
+    uint64_t* vis = P.vis + (size_t)view * P.W * P.H;
+    const int32_t nx = ts.px1 - ts.px0 + 1, ny = ts.py1 - ts.py0 + 1;
+    if (nx <= 4 && ny <= 4) {
+        raster_box(ts, vis, P.W, id, ts.px0, ts.px1, ts.py0, ts.py1);
+        return;
+    }
+    const int32_t rx0 = ts.px0 >> 6, rx1 = ts.px1 >> 6, ry0 = ts.py0 >> 6, ry1 = ts.py1 >> 6;
+    const uint32_t n = (uint32_t)((rx1 - rx0 + 1) * (ry1 - ry0 + 1));
+    const uint32_t base = atomicAdd(&P.counters[1], n);
+    if (base >= P.big_cap || n > P.big_cap - base) {
+        atomicOr(&P.counters[2], kStatusBigOverflow);
+        // neutralise whatever part of the reservation is inside the queue, then do the work here
+        for (uint32_t k = base; k < P.big_cap && k - base < n; ++k) P.big[k] = BigItem{0, kNoTri, 0, 0};
+        raster_box(ts, vis, P.W, id, ts.px0, ts.px1, ts.py0, ts.py1);
+        return;
+    }
+    uint32_t k = base;
+    for (int32_t ry = ry0; ry <= ry1; ++ry)
+        for (int32_t rx = rx0; rx <= rx1; ++rx) P.big[k++] = BigItem{view, id, (uint32_t)rx, (uint32_t)ry};
+}
+
+// Triangle with one or two vertices behind the near plane: full-precision path through clip_near.
+__device__ void emit_clipped(const FrameParams& P, const TileDev& t, const ViewDev& view, uint32_t view_idx,
+                             uint32_t tri, uint32_t draw) {
+    for (uint32_t fan = 0; fan < 2; ++fan) {
+        ResolvedTri r;
+        if (resolve_triangle(t, P.tile_w, P.tile_h, view, P.W, P.H, tri, fan, r)) emit_triangle(P, r.ts, view_idx, (draw << 1) | fan);
+    }
+}
+
+// One workgroup per surviving (view, tile, block): stage the block's post-transform vertices in LDS
+// (each vertex transformed once: coalesced 244-B row reads of the DEM), then one lane per grid cell sets
+// up and rasterises its two triangles.
+__global__ __launch_bounds__(256) void k_raster(FrameParams P) {
+    __shared__ SVert sv[kVY][kVX];
+    uint32_t count = P.counters[0];
+    if (count > P.work_cap) count = P.work_cap;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t item = blockIdx.x; item < count; item += gridDim.x) {
+        const WorkItem wi = P.work[item];
+        const uint32_t view_idx = wi.view_rank >> 16, rank = wi.view_rank & 0xFFFFu;
+        const TileDev& t = P.tiles[rank];
+        const ViewDev& view = P.views[view_idx];
+        const uint32_t bx = wi.block % P.bx_count, by = wi.block / P.bx_count;
+        const uint32_t x0 = bx * kBCX, y0 = by * kBCY;
+        // ---- phase 1: vertices
+        if (lane < kVX) {
+            const uint32_t vx = x0 + lane;
+            for (uint32_t r = wave; r < kVY; r += 4) {
+                const uint32_t vy = y0 + r;
+                SVert s;
+                s.X = 0; s.Y = 0; s.z = 0.0f; s.flag = kVtxNear;
+                if (vx < P.tile_w && vy < P.tile_h) {
+                    float clip[4];
+                    vertex_clip(t, view, vx, vy, t.heights[(size_t)vy * P.tile_w + vx], clip);
+                    clip_to_screen(clip, (float)P.W, (float)P.H, s);
+                }
+                sv[r][lane] = s;
+            }
+        }
+        __syncthreads();
+        // ---- phase 2: cells
+        const uint32_t ncx = min(kBCX, P.tile_w - 1 - x0), ncy = min(kBCY, P.tile_h - 1 - y0);
+        for (uint32_t c = threadIdx.x; c < ncx * ncy; c += 256) {
+            const uint32_t cy = c / ncx, cx = c - cy * ncx;
+            const uint32_t i = x0 + cx, j = y0 + cy;
+            const SVert a = sv[cy][cx], b = sv[cy + 1][cx], cc = sv[cy][cx + 1], d = sv[cy + 1][cx + 1];
+            const bool even = ((i + j) & 1u) == 0;
+            const uint32_t tri0 = (i * (P.tile_h - 1) + j) * 2;
+#pragma unroll
+            for (uint32_t k = 0; k < 2; ++k) {
+                const SVert& s0 = k == 0 ? a : d;
+                const SVert& s1 = k == 0 ? b : cc;
+                const SVert& s2 = k == 0 ? (even ? d : cc) : (even ? a : b);
+                const uint32_t tri = tri0 + k;
+                const uint32_t draw = rank * P.tris_per_tile + tri;
+                const int nnear = (s0.flag == kVtxNear) + (s1.flag == kVtxNear) + (s2.flag == kVtxNear);
+                if (nnear == 3) continue;
+                if (nnear != 0) {
+                    emit_clipped(P, t, view, view_idx, tri, draw);
+                    continue;
+                }
+                if ((s0.flag | s1.flag | s2.flag) != kVtxOk) continue;   // guard band: primitive discarded
+                TriSetup ts;
+                if (!triangle_setup(s0, s1, s2, P.W, P.H, ts)) continue;
+                emit_triangle(P, ts, view_idx, draw << 1);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// One wave per BigItem: all lanes rebuild the triangle (identical arithmetic, so identical bits), then
+// sweep the 8x8 sub-chunks of the item's 64x64 region that intersect the triangle's pixel box, one pixel
+// per lane.
+__global__ __launch_bounds__(256) void k_raster_big(FrameParams P) {
+    uint32_t count = P.counters[1];
+    if (count > P.big_cap) count = P.big_cap;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave_global = blockIdx.x * 4 + (threadIdx.x >> 6), wave_count = gridDim.x * 4;
+    for (uint32_t item = wave_global; item < count; item += wave_count) {
+        const BigItem bi = P.big[item];
+        if (bi.id == kNoTri) continue;
+        const uint32_t draw = bi.id >> 1, fan = bi.id & 1u;
+        const uint32_t rank = draw / P.tris_per_tile, tri = draw - rank * P.tris_per_tile;
+        ResolvedTri r;
+        if (!resolve_triangle(P.tiles[rank], P.tile_w, P.tile_h, P.views[bi.view], P.W, P.H, tri, fan, r)) continue;
+        uint64_t* vis = P.vis + (size_t)bi.view * P.W * P.H;
+        const int32_t bx0 = max(r.ts.px0, (int32_t)bi.rx * 64), bx1 = min(r.ts.px1, (int32_t)bi.rx * 64 + 63);
+        const int32_t by0 = max(r.ts.py0, (int32_t)bi.ry * 64), by1 = min(r.ts.py1, (int32_t)bi.ry * 64 + 63);
+        const int32_t lx = (int32_t)(lane & 7), ly = (int32_t)(lane >> 3);
+        for (int32_t sy = by0 & ~7; sy <= by1; sy += 8)
+            for (int32_t sx = bx0 & ~7; sx <= bx1; sx += 8) {
+                const int32_t px = sx + lx, py = sy + ly;
+                if (px < bx0 || px > bx1 || py < by0 || py > by1) continue;
+                float z, b[3];
+                if (triangle_pixel(r.ts, px, py, z, b)) vis_min(vis + (size_t)py * P.W + px, vis_key(z, bi.id));
+            }
+    }
+}
+
+// ---- resolve: fs_main for the winner of every pixel, then the post pass --------------------------------
+__device__ __forceinline__ float vis_depth(const uint64_t* vis, int32_t W, int32_t H, int32_t x, int32_t y) {
+    x = x < 0 ? 0 : (x > W - 1 ? W - 1 : x);   // clamp-to-edge depth sampler (texture.rs:113-117)
+    y = y < 0 ? 0 : (y > H - 1 ? H - 1 : y);
+    return bits_f((uint32_t)(vis[(size_t)y * W + x] >> 32));
+}
+
+__global__ __launch_bounds__(256) void k_resolve(FrameParams P, OutputParams O) {
+    __shared__ float s_thresh[256];
+    __shared__ float s_decode[256];
+    s_thresh[threadIdx.x] = bits_f(TOPO_SRGB_THRESH_BITS[threadIdx.x]);
+    s_decode[threadIdx.x] = bits_f(TOPO_SRGB_DECODE_BITS[threadIdx.x]);
+    __syncthreads();
+    const uint32_t view_idx = blockIdx.z;
+    const int32_t px = blockIdx.x * 64 + (threadIdx.x & 63), py = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (px >= P.W || py >= P.H) return;
+    const uint64_t* vis = P.vis + (size_t)view_idx * P.W * P.H;
+    const ViewDev& view = P.views[view_idx];
+    const uint64_t key = vis[(size_t)py * P.W + px];
+    const float depth = bits_f((uint32_t)(key >> 32));
+    const uint32_t id = (uint32_t)key;
+    // render target texel (Rgba8UnormSrgb): clear colour or the shaded winner
+    float lin[4] = {0.0f, 0.71f, 0.885f, 1.0f};          // terrain_renderer.rs:379-384
+    if (id != kNoTri) {
+        const uint32_t draw = id >> 1, fan = id & 1u;
+        const uint32_t rank = draw / P.tris_per_tile, tri = draw - rank * P.tris_per_tile;
+        ResolvedTri r;
+        float z, b[3];
+        if (resolve_triangle(P.tiles[rank], P.tile_w, P.tile_h, view, P.W, P.H, tri, fan, r) &&
+            triangle_pixel(r.ts, px, py, z, b)) {
+            f3 wpos, wnrm;
+            interpolate(r.v[0], r.v[1], r.v[2], b, wpos, wnrm);
+            const f3 sun = {view.sun[0], view.sun[1], view.sun[2]};
+            shade_fragment(view.view_mode, sun, view.cam_x, view.cam_y, (float)px + 0.5f, (float)py + 0.5f, wpos, wnrm, lin);
+        }
+    }
+    const uint32_t c8 = srgb_encode(s_thresh, lin[0]) | (srgb_encode(s_thresh, lin[1]) << 8) |
+                        (srgb_encode(s_thresh, lin[2]) << 16) | (to_unorm8(lin[3]) << 24);
+    float dn[8];
+    int k = 0;
+#pragma unroll
+    for (int i = -1; i <= 1; ++i)
+#pragma unroll
+        for (int j = -1; j <= 1; ++j) {
+            if (i == 0 && j == 0) continue;
+            dn[k++] = vis_depth(vis, P.W, P.H, px + i, py + j);
+        }
+    const uint32_t out = post_pixel(s_thresh, s_decode, c8, depth, dn);
+    *reinterpret_cast<uint32_t*>(O.rgba + (size_t)view_idx * O.rgba_view_stride + (size_t)py * O.rgba_pitch + (size_t)px * 4) = out;
+    if (O.depth)
+        *reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(O.depth) + (size_t)view_idx * O.depth_view_stride +
+                                  (size_t)py * O.depth_pitch + (size_t)px * 4) = depth;
+}
+
+__global__ void k_probe_sincos(const float* x, float* s, float* c, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) sincos_f(x[i], s[i], c[i]);
+}
+
+}  // namespace
+
+// ======================================================================================================
+// launchers
+// ======================================================================================================
+
+void launch_block_minmax(const float* heights, float* minmax, uint32_t w, uint32_t h, hipStream_t s) {
+    const uint32_t bxc = (w - 1 + kBCX - 1) / kBCX, byc = (h - 1 + kBCY - 1) / kBCY;
+    hipLaunchKernelGGL(k_block_minmax, dim3(bxc * byc), dim3(64), 0, s, heights, minmax, w, h, bxc);
+}
+
+void launch_normals_interior(const TileDev& t, uint32_t w, uint32_t h, int lds_rows, hipStream_t s) {
+    const dim3 block(256);
+#define TOPO_K1(R)                                                                                                   \
+    hipLaunchKernelGGL(k_normals_interior<R>, dim3((w + 63) / 64, (h + (R)-1) / (R)), block, 0, s, t.heights, t.normals, \
+                       (int)w, (int)h, t.raster_y, t.model_y, t.scale_x, t.scale_y)
+    switch (lds_rows) {
+        case 4: TOPO_K1(4); break;
+        case 8: TOPO_K1(8); break;
+        case 32: TOPO_K1(32); break;
+        case 64: TOPO_K1(64); break;
+        default: TOPO_K1(16); break;
+    }
+#undef TOPO_K1
+}
+
+void launch_normals_edge(const TileDev& lt, const TileDev& rb, const TileDev& uni, uint32_t w, uint32_t h,
+                         bool top_bottom, hipStream_t s) {
+    hipLaunchKernelGGL(k_normals_edge, dim3((w + 63) / 64), dim3(64), 0, s, lt.heights, rb.heights, lt.normals,
+                       rb.normals, (int)w, (int)h, uni.raster_y, uni.model_y, uni.scale_x, uni.scale_y, top_bottom ? 1 : 0);
+}
+
+void launch_normals_corner(const TileDev& lt, const TileDev& rt, const TileDev& lb, const TileDev& rb,
+                           const TileDev& uni, uint32_t w, uint32_t h, hipStream_t s) {
+    hipLaunchKernelGGL(k_normals_corner, dim3(1), dim3(1), 0, s, lt.heights, rt.heights, lb.heights, rb.heights,
+                       lt.normals, rt.normals, lb.normals, rb.normals, (int)w, (int)h, uni.raster_y, uni.model_y,
+                       uni.scale_x, uni.scale_y);
+}
+
+void launch_clear(const FrameParams& p, hipStream_t s) {
+    const size_t n = (size_t)p.n_views * p.W * p.H;
+    hipLaunchKernelGGL(k_clear, dim3(2048), dim3(256), 0, s, p.vis, n, p.counters);
+}
+
+void launch_cull(const FrameParams& p, hipStream_t s) {
+    const size_t total = (size_t)p.n_views * p.n_tiles * p.bx_count * p.by_count;
+    if (total == 0) return;
+    hipLaunchKernelGGL(k_cull, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p);
+}
+
+void launch_raster(const FrameParams& p, hipStream_t s) {
+    if (p.n_tiles == 0) return;
+    hipLaunchKernelGGL(k_raster, dim3(256 * 8), dim3(256), 0, s, p);
+}
+
+void launch_raster_big(const FrameParams& p, hipStream_t s) {
+    if (p.n_tiles == 0) return;
+    hipLaunchKernelGGL(k_raster_big, dim3(256 * 4), dim3(256), 0, s, p);
+}
+
+void launch_resolve(const FrameParams& p, const OutputParams& o, hipStream_t s) {
+    hipLaunchKernelGGL(k_resolve, dim3((p.W + 63) / 64, (p.H + 3) / 4, p.n_views), dim3(256), 0, s, p, o);
+}
+
+void launch_probe_sincos(const float* x, float* s, float* c, size_t n, hipStream_t st) {
+    hipLaunchKernelGGL(k_probe_sincos, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, s, c, n);
+}
+
+}  // namespace topo

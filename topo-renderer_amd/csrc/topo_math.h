@@ -1,0 +1,197 @@
+// topo_math.h -- arithmetic of the terrain path, frozen so that results are reproducible bit for bit.
+//
+// WGSL leaves sin/cos/normalize precision, FMA contraction and sRGB rounding to the implementation; the
+// build fixes one definition (DESIGN.md "Arithmetic spec"): IEEE binary32 +,-,*,/,sqrt, NO contraction
+// (translation units including this header are compiled with -ffp-contract=off), evaluation order as the
+// WGSL writes it, Cody-Waite + Cephes minimax sin/cos, exact-curve sRGB tables.
+//
+// Everything here is `TOPO_HD` (host + device) so the same functions run inside the HIP kernels and,
+// for unit tests only, under g++ (tests/host_emul.cpp).  Nothing in this file touches memory it is not
+// handed, and nothing here knows about the CPU oracle.
+#pragma once
+
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define TOPO_HD __host__ __device__ __forceinline__
+#else
+#define TOPO_HD inline
+#endif
+
+#include "srgb_tables.h"
+
+namespace topo {
+
+constexpr float kR0 = 6371000.0f;    // render_shader.wgsl:1, compute_normals_shader.wgsl:1
+constexpr float kNear = 50.0f;       // postprocessing_shader.wgsl:19
+constexpr float kFar = 500000.0f;    // postprocessing_shader.wgsl:20
+
+struct f3 {
+    float x, y, z;
+};
+
+TOPO_HD uint32_t f_bits(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __float_as_uint(f);
+#else
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    return u;
+#endif
+}
+TOPO_HD float bits_f(uint32_t u) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __uint_as_float(u);
+#else
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+#endif
+}
+
+// WGSL radians()
+TOPO_HD float deg2rad(float d) { return d * 0.017453292519943295f; }
+
+// sin & cos of x (|x| < ~1e4): k = rint(x*2/pi); r = x - k*pi/2 in three exact-product steps;
+// Cephes sinf/cosf kernels on |r| <= pi/4; quadrant swap.
+TOPO_HD void sincos_f(float x, float& sn, float& cs) {
+    float k = rintf(x * 0.63661977236758134f);
+    float r = x - k * 1.5703125f;
+    r = r - k * 4.837512969970703125e-4f;
+    r = r - k * 7.54978995489188e-8f;
+    const float z = r * r;
+    float a = -1.9515295891e-4f;
+    a = a * z + 8.3321608736e-3f;
+    a = a * z + -1.6666654611e-1f;
+    const float s = r + r * z * a;
+    float b = 2.443315711809948e-5f;
+    b = b * z + -1.388731625493765e-3f;
+    b = b * z + 4.166664568298827e-2f;
+    const float c = (1.0f - 0.5f * z) + z * z * b;
+    const int q = (int)k & 3;
+    const bool swap = (q & 1) != 0;
+    float so = swap ? c : s;
+    float co = swap ? s : c;
+    if (q == 2 || q == 3) so = -so;
+    if (q == 1 || q == 2) co = -co;
+    sn = so;
+    cs = co;
+}
+TOPO_HD float cos_f(float x) {
+    float s, c;
+    sincos_f(x, s, c);
+    return c;
+}
+
+TOPO_HD float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+TOPO_HD f3 cross3(f3 a, f3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+TOPO_HD f3 normalize3(f3 a) {
+    const float len = sqrtf(dot3(a, a));
+    return {a.x / len, a.y / len, a.z / len};
+}
+TOPO_HD float fract_f(float x) { return x - floorf(x); }
+TOPO_HD float sat(float x) { return x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x); }
+
+// rgba8unorm store / load
+TOPO_HD uint32_t to_unorm8(float v) { return (uint32_t)floorf(sat(v) * 255.0f + 0.5f); }
+TOPO_HD float from_unorm8(uint32_t c) { return (float)c / 255.0f; }
+
+// column-major 4x4 times (x, y, z, 1)
+TOPO_HD void mat4_point(const float* m, float x, float y, float z, float* o) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float t = m[r] * x;
+        t = t + m[4 + r] * y;
+        t = t + m[8 + r] * z;
+        t = t + m[12 + r] * 1.0f;
+        o[r] = t;
+    }
+}
+
+TOPO_HD float linear_depth(float d) { return kFar * kNear / (kFar - d * (kFar - kNear)); }
+
+// ---- sRGB ----------------------------------------------------------------------------------------
+// `thresh` points at 256 floats (TOPO_SRGB_THRESH_BITS reinterpreted; entry 255 = +inf), `decode` at 256.
+// encode = number of thresholds <= l; 8 fixed probes, branch free.
+TOPO_HD uint32_t srgb_encode(const float* thresh, float l) {
+    uint32_t lo = 0;
+#pragma unroll
+    for (uint32_t step = 128; step >= 1; step >>= 1) {
+        // invariant: thresh[0..lo) <= l.  Probe index lo+step-1 (<= 254).
+        if (thresh[lo + step - 1] <= l) lo += step;
+    }
+    return lo;
+}
+
+// ---- normal stencil (compute_normals*.wgsl) ------------------------------------------------------
+// Returns the packed rgba8unorm texel (alpha 0) for the four neighbour heights; `x`,`y` are the metric
+// half-steps the shaders build from the pixel scale and the row latitude.
+TOPO_HD uint32_t normal_texel(float x, float y, float hT, float hL, float hR, float hB) {
+    const f3 top = {0.0f, y, hT}, left = {-x, 0.0f, hL}, right = {x, 0.0f, hR}, bottom = {0.0f, -y, hB};
+    const f3 dxv = {right.x - left.x, right.y - left.y, right.z - left.z};
+    const f3 dyv = {top.x - bottom.x, top.y - bottom.y, top.z - bottom.z};
+    f3 n = normalize3(cross3(dxv, dyv));
+    n = {0.5f * (n.x + 1.0f), 0.5f * (n.y + 1.0f), 0.5f * (n.z + 1.0f)};
+    return to_unorm8(n.x) | (to_unorm8(n.y) << 8) | (to_unorm8(n.z) << 16) | (to_unorm8(0.0f) << 24);
+}
+
+// ---- fragment shading (render_shader.wgsl:75-115) ------------------------------------------------
+TOPO_HD float hash12n(float sx, float sy) {
+    float px = fract_f(sx * 5.3987f);
+    float py = fract_f(sy * 5.4421f);
+    const float d = py * (px + 21.5351f) + px * (py + 14.3137f);
+    px += d;
+    py += d;
+    return fract_f(px * py * 95.4307f);
+}
+
+// Linear colour of fs_main for one fragment.  frag = pixel centre, cam = camera_pos.xy.
+TOPO_HD void shade_fragment(int view_mode, f3 sun, float cam_x, float cam_y, float frag_x, float frag_y, f3 wpos,
+                            f3 wnrm, float out[4]) {
+    if (view_mode == 2) {
+        out[0] = 0.5f * (wnrm.x + 1.0f);
+        out[1] = 0.5f * (wnrm.y + 1.0f);
+        out[2] = 0.5f * (wnrm.z + 1.0f);
+        out[3] = 1.0f;
+        return;
+    }
+    const float d = dot3(normalize3(wnrm), sun);
+    const float lin = 0.01f + 0.7f * (d > 0.0f ? d : 0.0f);
+    out[3] = 1.0f;
+    if (view_mode == 1) {
+        out[0] = out[1] = out[2] = lin;
+        return;
+    }
+    const float px = frag_x + cam_x - wpos.x, py = frag_y + cam_y - wpos.y;
+    const float qx = px + 0.13f, qy = py + 0.13f;
+    const float off[3] = {0.0f, 0.07f, 0.11f};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float h1 = k == 0 ? hash12n(px, py) : hash12n(px + off[k], py + off[k]);
+        const float h2 = k == 0 ? hash12n(qx, qy) : hash12n(qx + off[k], qy + off[k]);
+        out[k] = lin + 1.0f * (h1 + h2 - 1.0f) / 255.0f;
+    }
+}
+
+// ---- post pass (postprocessing_shader.wgsl:68-96) -------------------------------------------------
+// `c8` = the render-target texel (sRGB8 rgb + unorm8 alpha), dc = centre depth, dn = the 8 neighbour
+// depths in the shader's loop order (i outer = x offset -1..1, j inner = y offset -1..1, centre skipped).
+TOPO_HD uint32_t post_pixel(const float* thresh, const float* decode, uint32_t c8, float dc, const float dn[8]) {
+    const float center = linear_depth(dc);
+    float contour = 8.0f * center;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) contour -= linear_depth(dn[k]);
+    float t = sat((contour / center - 0.05f) / (0.15f - 0.05f));
+    const float a = t * t * (3.0f - 2.0f * t);
+    const float r = decode[c8 & 255u] * (1.0f - a) + 0.0f * a;
+    const float g = decode[(c8 >> 8) & 255u] * (1.0f - a) + 0.0f * a;
+    const float b = decode[(c8 >> 16) & 255u] * (1.0f - a) + 0.0f * a;
+    const float al = from_unorm8(c8 >> 24) * (1.0f - a) + 1.0f * a;
+    return srgb_encode(thresh, r) | (srgb_encode(thresh, g) << 8) | (srgb_encode(thresh, b) << 16) |
+           (to_unorm8(al) << 24);
+}
+
+}  // namespace topo

@@ -1,0 +1,283 @@
+// topo_pipeline.h -- per-vertex / per-triangle / per-pixel stages of the terrain path.
+//
+// The reference draws every tile's mesh through the fixed-function rasteriser (pipeline.rs:221-246);
+// here the same semantics are spelled out as plain functions (DESIGN.md "Raster spec") that the HIP
+// kernels in topo_kernels.hip call.  All functions are pure (TOPO_HD) so tests can also execute them
+// under g++ (tests/host_emul.cpp); the product only ever runs them on the GPU.
+#pragma once
+
+#include "topo_math.h"
+
+namespace topo {
+
+// ---- device-side descriptors ---------------------------------------------------------------------
+struct TileDev {                 // one loaded 1x1 degree tile (RenderBuffer, render_buffer.rs:23-31)
+    const float* heights;        // w*h f32, row-major, row 0 = north      (R32Float texture)
+    uint32_t* normals;           // w*h packed rgba8unorm, zero-initialised (Rgba8Unorm texture)
+    const float* block_minmax;   // 2 floats per raster block: min, max height of its vertices
+    float raster_x, raster_y;    // TerrainUniforms (render/data.rs:113-121)
+    float model_x, model_y;
+    float scale_x, scale_y;
+    float rot[9];                // upper-left 3x3 of normal_to_world_rot, column-major
+    float pad_;
+};
+
+struct ViewDev {                 // one frame's Uniforms (render/data.rs:33-41), the fields the shaders read
+    float proj[16];              // camera_proj, column-major
+    float cam_x, cam_y;          // camera_pos.xy (dither seed only)
+    float sun[3];
+    int32_t view_mode;
+};
+
+constexpr uint32_t kNoTri = 0xFFFFFFFFu;
+constexpr uint64_t kVisClear = 0x3F800000FFFFFFFFull;   // depth 1.0 | no triangle
+
+// vertex flags
+constexpr int kVtxOk = 0, kVtxNear = 1, kVtxGuard = 2;
+
+struct alignas(16) SVert {       // post-transform vertex as the rasteriser sees it
+    int32_t X, Y;                // 1/256 pixel, round-half-even
+    float z;                     // z_ndc
+    int32_t flag;                // kVtxOk / kVtxNear (z_clip < 0) / kVtxGuard (outside +-2^20 px or non-finite)
+};
+
+struct VFull {                   // full vs_main output
+    float clip[4];
+    f3 wpos;
+    f3 wnrm;
+};
+
+// ---- vertex stage: render_shader.wgsl:35-73 --------------------------------------------------------
+TOPO_HD f3 vertex_world(const TileDev& t, uint32_t vx, uint32_t vy, float height) {
+    const float mx = ((float)vx - t.raster_x) * t.scale_x + t.model_x;
+    const float my = ((float)vy - t.raster_y) * -t.scale_y + t.model_y;
+    const float lon = deg2rad(mx), lat = deg2rad(my);
+    const float R = kR0 + height;
+    float sla, cla, slo, clo;
+    sincos_f(lat, sla, cla);
+    sincos_f(lon, slo, clo);
+    return {R * cla * clo, R * cla * slo, R * sla};
+}
+
+TOPO_HD f3 vertex_normal(const TileDev& t, uint32_t packed) {
+    const float nx = 2.0f * from_unorm8(packed & 255u) - 1.0f;
+    const float ny = 2.0f * from_unorm8((packed >> 8) & 255u) - 1.0f;
+    const float nz = 2.0f * from_unorm8((packed >> 16) & 255u) - 1.0f;
+    const float* m = t.rot;
+    return {(m[0] * nx + m[3] * ny) + m[6] * nz, (m[1] * nx + m[4] * ny) + m[7] * nz,
+            (m[2] * nx + m[5] * ny) + m[8] * nz};
+}
+
+// clip -> framebuffer (WebGPU framebufferCoords), snapped.  Returns the flag.
+TOPO_HD int clip_to_screen(const float clip[4], float W, float H, SVert& s) {
+    s.X = 0;
+    s.Y = 0;
+    s.z = 0.0f;
+    if (!(clip[2] >= 0.0f)) {
+        s.flag = kVtxNear;
+        return kVtxNear;
+    }
+    const float w = clip[3];
+    const float nx = clip[0] / w, ny = clip[1] / w, nz = clip[2] / w;
+    const float xf = (0.5f * (nx + 1.0f)) * W;
+    const float yf = (0.5f * (1.0f - ny)) * H;
+    if (!(fabsf(xf) <= 1048576.0f) || !(fabsf(yf) <= 1048576.0f)) {
+        s.flag = kVtxGuard;
+        return kVtxGuard;
+    }
+    s.X = (int32_t)rintf(xf * 256.0f);
+    s.Y = (int32_t)rintf(yf * 256.0f);
+    s.z = nz;
+    s.flag = kVtxOk;
+    return kVtxOk;
+}
+
+// ---- mesh topology: render_buffer.rs:185-219 -------------------------------------------------------
+// Triangle `tri` of a tile (index-buffer order): cell = tri/2 with i = cell / (h-1) (x, outer loop) and
+// j = cell % (h-1) (y, inner loop); k = tri & 1.  Vertex (i, j) samples texel (x=i, y=j).
+TOPO_HD void triangle_vertices(uint32_t tri, uint32_t hm1, uint32_t vx[3], uint32_t vy[3]) {
+    const uint32_t cell = tri >> 1, k = tri & 1u;
+    const uint32_t i = cell / hm1, j = cell - i * hm1;
+    const bool even = ((i + j) & 1u) == 0;
+    // a=(i,j) b=(i,j+1) c=(i+1,j) d=(i+1,j+1)
+    if (k == 0) {                       // [a, b, d] | [a, b, c]
+        vx[0] = i; vy[0] = j;
+        vx[1] = i; vy[1] = j + 1;
+        vx[2] = i + 1; vy[2] = even ? j + 1 : j;
+    } else if (even) {                  // [d, c, a]
+        vx[0] = i + 1; vy[0] = j + 1;
+        vx[1] = i + 1; vy[1] = j;
+        vx[2] = i; vy[2] = j;
+    } else {                            // [d, c, b]
+        vx[0] = i + 1; vy[0] = j + 1;
+        vx[1] = i + 1; vy[1] = j;
+        vx[2] = i; vy[2] = j + 1;
+    }
+}
+
+// ---- triangle setup + coverage ---------------------------------------------------------------------
+// Front face = counter-clockwise on screen = negative doubled area in y-down framebuffer space.
+// Edge a->b: F(p) = dy*(px-ax) - dx*(py-ay) >= 0 inside; it owns its boundary iff it is a left edge
+// (dy > 0) or a top edge (dy == 0 && dx < 0).  Pixel centres sit at (256*px+128, 256*py+128).
+struct TriSetup {
+    int64_t ax[3], ay[3], dx[3], dy[3];   // edges e0 = v1->v2 (weight of v0), e1 = v2->v0, e2 = v0->v1
+    int64_t bias[3];
+    float fA;                             // doubled area as float
+    float z0, dz1, dz2;
+    int32_t px0, px1, py0, py1;           // inclusive pixel bbox clipped to the target
+};
+
+TOPO_HD int64_t floor_div256(int64_t a) { return a >> 8; }   // arithmetic shift == floor division by 256
+
+TOPO_HD bool triangle_setup(const SVert& s0, const SVert& s1, const SVert& s2, int32_t W, int32_t H, TriSetup& ts) {
+    const int64_t X0 = s0.X, Y0 = s0.Y, X1 = s1.X, Y1 = s1.Y, X2 = s2.X, Y2 = s2.Y;
+    const int64_t area2 = (X1 - X0) * (Y2 - Y0) - (Y1 - Y0) * (X2 - X0);
+    if (area2 >= 0) return false;
+    int64_t mnx = X0 < X1 ? X0 : X1; mnx = mnx < X2 ? mnx : X2;
+    int64_t mxx = X0 > X1 ? X0 : X1; mxx = mxx > X2 ? mxx : X2;
+    int64_t mny = Y0 < Y1 ? Y0 : Y1; mny = mny < Y2 ? mny : Y2;
+    int64_t mxy = Y0 > Y1 ? Y0 : Y1; mxy = mxy > Y2 ? mxy : Y2;
+    int64_t px0 = floor_div256(mnx - 128 + 255), px1 = floor_div256(mxx - 128);
+    int64_t py0 = floor_div256(mny - 128 + 255), py1 = floor_div256(mxy - 128);
+    if (px0 < 0) px0 = 0;
+    if (py0 < 0) py0 = 0;
+    if (px1 > W - 1) px1 = W - 1;
+    if (py1 > H - 1) py1 = H - 1;
+    if (px0 > px1 || py0 > py1) return false;
+    ts.px0 = (int32_t)px0; ts.px1 = (int32_t)px1; ts.py0 = (int32_t)py0; ts.py1 = (int32_t)py1;
+    const int64_t ex[3] = {X1, X2, X0}, ey[3] = {Y1, Y2, Y0};
+    const int64_t fx[3] = {X2, X0, X1}, fy[3] = {Y2, Y0, Y1};
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+        ts.ax[e] = ex[e]; ts.ay[e] = ey[e];
+        ts.dx[e] = fx[e] - ex[e]; ts.dy[e] = fy[e] - ey[e];
+        const bool own = (ts.dy[e] > 0) || (ts.dy[e] == 0 && ts.dx[e] < 0);
+        ts.bias[e] = own ? 0 : -1;
+    }
+    ts.fA = (float)(-area2);
+    ts.z0 = s0.z; ts.dz1 = s1.z - s0.z; ts.dz2 = s2.z - s0.z;
+    return true;
+}
+
+// Coverage + depth of pixel (px,py).  Returns false when not covered or clipped by the far plane.
+TOPO_HD bool triangle_pixel(const TriSetup& ts, int32_t px, int32_t py, float& z, float b[3]) {
+    const int64_t cx = (int64_t)px * 256 + 128, cy = (int64_t)py * 256 + 128;
+    int64_t F[3];
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+        F[e] = ts.dy[e] * (cx - ts.ax[e]) - ts.dx[e] * (cy - ts.ay[e]);
+        if (F[e] + ts.bias[e] < 0) return false;
+    }
+    b[0] = (float)F[0] / ts.fA;
+    b[1] = (float)F[1] / ts.fA;
+    b[2] = (float)F[2] / ts.fA;
+    float zz = ts.z0 + (b[1] * ts.dz1 + b[2] * ts.dz2);
+    if (!(zz < 1.0f)) return false;
+    if (zz < 0.0f) zz = 0.0f;
+    z = zz;
+    return true;
+}
+
+TOPO_HD uint64_t vis_key(float z, uint32_t id) { return ((uint64_t)f_bits(z) << 32) | id; }
+
+// ---- near-plane clipping of one triangle -------------------------------------------------------------
+// Sutherland-Hodgman against z_clip >= 0, intersections always computed from the inside vertex towards the
+// outside one (t = z_in / (z_in - z_out)), output fan-triangulated from the first emitted vertex.
+// Returns the number of output vertices (0, 3 or 4).
+TOPO_HD VFull lerp_vertex(const VFull& I, const VFull& O, float t) {
+    VFull r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r.clip[k] = I.clip[k] + t * (O.clip[k] - I.clip[k]);
+    r.clip[2] = 0.0f;
+    r.wpos = {I.wpos.x + (O.wpos.x - I.wpos.x) * t, I.wpos.y + (O.wpos.y - I.wpos.y) * t,
+              I.wpos.z + (O.wpos.z - I.wpos.z) * t};
+    r.wnrm = {I.wnrm.x + (O.wnrm.x - I.wnrm.x) * t, I.wnrm.y + (O.wnrm.y - I.wnrm.y) * t,
+              I.wnrm.z + (O.wnrm.z - I.wnrm.z) * t};
+    return r;
+}
+
+TOPO_HD int clip_near(const VFull v[3], VFull out[4]) {
+    const bool in0 = v[0].clip[2] >= 0.0f, in1 = v[1].clip[2] >= 0.0f, in2 = v[2].clip[2] >= 0.0f;
+    const bool in[3] = {in0, in1, in2};
+    const int nin = (int)in0 + (int)in1 + (int)in2;
+    if (nin == 0) return 0;
+    if (nin == 3) {
+        out[0] = v[0]; out[1] = v[1]; out[2] = v[2];
+        return 3;
+    }
+    int n = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int j = i == 2 ? 0 : i + 1;
+        if (in[i]) out[n++] = v[i];
+        if (in[i] != in[j]) {
+            const VFull& I = in[i] ? v[i] : v[j];
+            const VFull& O = in[i] ? v[j] : v[i];
+            const float t = I.clip[2] / (I.clip[2] - O.clip[2]);
+            out[n++] = lerp_vertex(I, O, t);
+        }
+    }
+    return n;
+}
+
+// ---- perspective-correct varyings --------------------------------------------------------------------
+TOPO_HD void interpolate(const VFull& v0, const VFull& v1, const VFull& v2, const float b[3], f3& wpos, f3& wnrm) {
+    const float q0 = b[0] / v0.clip[3], q1 = b[1] / v1.clip[3], q2 = b[2] / v2.clip[3];
+    const float qs = (q0 + q1) + q2;
+    wpos.x = ((v0.wpos.x * q0 + v1.wpos.x * q1) + v2.wpos.x * q2) / qs;
+    wpos.y = ((v0.wpos.y * q0 + v1.wpos.y * q1) + v2.wpos.y * q2) / qs;
+    wpos.z = ((v0.wpos.z * q0 + v1.wpos.z * q1) + v2.wpos.z * q2) / qs;
+    wnrm.x = ((v0.wnrm.x * q0 + v1.wnrm.x * q1) + v2.wnrm.x * q2) / qs;
+    wnrm.y = ((v0.wnrm.y * q0 + v1.wnrm.y * q1) + v2.wnrm.y * q2) / qs;
+    wnrm.z = ((v0.wnrm.z * q0 + v1.wnrm.z * q1) + v2.wnrm.z * q2) / qs;
+}
+
+// Full vs_main for vertex (vx,vy) of tile t under view v.
+TOPO_HD VFull vertex_full(const TileDev& t, uint32_t tile_w, const ViewDev& v, uint32_t vx, uint32_t vy) {
+    VFull o;
+    const size_t idx = (size_t)vy * tile_w + vx;
+    o.wpos = vertex_world(t, vx, vy, t.heights[idx]);
+    o.wnrm = vertex_normal(t, t.normals[idx]);
+    mat4_point(v.proj, o.wpos.x, o.wpos.y, o.wpos.z, o.clip);
+    return o;
+}
+
+// Visibility-only version: clip position from the height alone.
+TOPO_HD void vertex_clip(const TileDev& t, const ViewDev& v, uint32_t vx, uint32_t vy, float height, float clip[4]) {
+    const f3 p = vertex_world(t, vx, vy, height);
+    mat4_point(v.proj, p.x, p.y, p.z, clip);
+}
+
+// The triangle (after near clipping) that draw-order id `id` = (draw << 1 | fan index) names, set up for
+// pixel evaluation.  Returns false if it does not exist / is culled (cannot happen for an id that won a pixel).
+struct ResolvedTri {
+    VFull v[3];
+    TriSetup ts;
+};
+TOPO_HD bool resolve_triangle(const TileDev& t, uint32_t tile_w, uint32_t tile_h, const ViewDev& view, int32_t W,
+                              int32_t H, uint32_t tri, uint32_t fan, ResolvedTri& r) {
+    uint32_t vx[3], vy[3];
+    triangle_vertices(tri, tile_h - 1, vx, vy);
+    r.v[0] = vertex_full(t, tile_w, view, vx[0], vy[0]);
+    r.v[1] = vertex_full(t, tile_w, view, vx[1], vy[1]);
+    r.v[2] = vertex_full(t, tile_w, view, vx[2], vy[2]);
+    const bool all_in = r.v[0].clip[2] >= 0.0f && r.v[1].clip[2] >= 0.0f && r.v[2].clip[2] >= 0.0f;
+    if (all_in) {   // the common case, kept free of runtime-indexed arrays
+        if (fan != 0) return false;
+        SVert s0, s1, s2;
+        if (clip_to_screen(r.v[0].clip, (float)W, (float)H, s0) != kVtxOk) return false;
+        if (clip_to_screen(r.v[1].clip, (float)W, (float)H, s1) != kVtxOk) return false;
+        if (clip_to_screen(r.v[2].clip, (float)W, (float)H, s2) != kVtxOk) return false;
+        return triangle_setup(s0, s1, s2, W, H, r.ts);
+    }
+    VFull poly[4];
+    const int n = clip_near(r.v, poly);
+    if (n < 3 || (int)fan + 2 >= n) return false;
+    SVert s[4];
+    for (int k = 0; k < n; ++k)
+        if (clip_to_screen(poly[k].clip, (float)W, (float)H, s[k]) != kVtxOk) return false;
+    r.v[0] = poly[0]; r.v[1] = poly[fan + 1]; r.v[2] = poly[fan + 2];
+    return triangle_setup(s[0], s[fan + 1], s[fan + 2], W, H, r.ts);
+}
+
+}  // namespace topo
