@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""bench.py -- panorama Mpix/s + achieved HBM GB/s of the MI355X terrain path (BASELINE.json metric).
+
+One "step" = one complete 360-degree panorama: the 8 fixed 45-degree sectors (each a full reference frame:
+clear, cull, raster, resolve + contour post) rendered from the resident DEM mosaic, plus -- for N > 1 -- the
+RCCL all-gather of the per-rank strips.  Tiles and their normal textures are resident in HBM before the timed
+region (the reference computes normals once per tile load, terrain_renderer.rs:192-202); the load phase is
+timed separately and reported as `load_ms`.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+N GPUs shard the panorama by azimuth sector (rank g renders sectors [8g/N, 8(g+1)/N)), DEM replicated, so
+the total work is fixed: scaling = "strong".
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (mosaic degrees per side, panorama width, panorama height)      BASELINE.json configs
+    "c1": (1, 1024, 256),
+    "c2": (1, 4096, 1024),
+    "c3": (5, 8192, 2048),
+    "c4": (10, 16384, 4096),
+}
+LAT0, LON0 = 40, 10            # mosaic SW corner
+TILE = 1200
+N_SECTORS = 8
+HBM_PEAK_GBPS = 8000.0         # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
+    ap.add_argument("--view-mode", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--check", action="store_true", help="verify sector 0 against the oracle (slow)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import topo_renderer_amd as T
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if N_SECTORS % world != 0:
+        raise SystemExit("the sector count (8) must be divisible by the GPU count")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    deg, PW, PH = WORKLOADS[args.workload]
+    SW = PW // N_SECTORS
+    n_tiles = deg * deg
+    locs = T.synth.mosaic_locations(LAT0, LON0, deg, deg)
+
+    # ---- synthetic COP90-shaped mosaic, uploaded once (not timed: inputs are resident before the timed region)
+    t0 = time.time()
+    r = T.TerrainRenderer(SW, PH, device=local_rank)
+    r.set_stream(torch.cuda.current_stream().cuda_stream)
+    vlat, vlon = LAT0 + deg / 2 + 0.123, LON0 + deg / 2 + 0.217      # mosaic centre + (0.123, 0.217) degrees
+    ground = None
+    upload_s = 0.0
+    for (la, lo) in locs:
+        h = T.synth_tile(la, lo, TILE, TILE)
+        if la == int(math.floor(vlat)) and lo == int(math.floor(vlon)):
+            ground = T.synth.height_at(h, la, lo, vlon, vlat)
+        t1 = time.time()
+        r.add_terrain(la, lo, h, *T.synth.tile_transform(la, lo, TILE, TILE))
+        upload_s += time.time() - t1
+    r.synchronize()
+    setup_s = time.time() - t0
+    eye = T.geometry_transform(ground + 50.0, vlon, vlat)            # render_engine.rs:327
+    views = T.panorama_uniforms(eye, 0.0, SW, PH, vlon, vlat, args.view_mode)
+
+    # ---- load phase (normals K1-K3 over resident heights), timed on its own
+    load_ms = []
+    for _ in range(3):
+        r.recompute_normals()
+        load_ms.append(r.timings()["load"])
+    load_ms = min(load_ms)
+
+    # ---- outputs: sector-major strip so each rank's share is contiguous for the all-gather
+    per = N_SECTORS // world
+    my = list(range(rank * per, (rank + 1) * per))
+    strip = torch.empty((N_SECTORS, PH, SW, 4), dtype=torch.uint8, device="cuda")
+    depth = torch.empty((per, PH, SW), dtype=torch.float32, device="cuda")
+    mine = strip[my[0]:my[0] + per]
+
+    def step():
+        r.render_views_device([views[k] for k in my], SW, PH, mine.data_ptr(), PH * SW * 4, SW * 4,
+                              depth.data_ptr(), PH * SW * 4, SW * 4)
+        if dist is not None:
+            dist.all_gather_into_tensor(strip.view(-1), mine.reshape(-1))
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    kernel_ms = {k: 0.0 for k in ("clear", "cull", "raster", "raster_big", "resolve", "total")}
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        # HIP-event durations of this step's kernels (events sit on the same stream; reading them waits for
+        # the step, which the timed loop does anyway before the next submission's host-side staging)
+        tm = r.timings()
+        for k in kernel_ms:
+            kernel_ms[k] += tm[k]
+    fence()
+    elapsed = time.perf_counter() - t_start
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    for k in kernel_ms:
+        kernel_ms[k] /= args.steps
+    counters = r.counters()
+
+    mpix = PW * PH / 1e6
+    value = mpix / (ms_per_step / 1e3)
+
+    # ---- roofline of the dominant kernel (k_raster): algorithmic bytes = the DEM heights it must read once,
+    # 4 B per texel of every tile this rank rasterises (SURVEY.md 8d "DEM read"); at N ranks each launch covers
+    # the tiles seen by its sectors, priced here as the full mosaic / N.
+    dem_bytes = 4.0 * n_tiles * TILE * TILE / world
+    raster_s = kernel_ms["raster"] / 1e3
+    achieved = dem_bytes / raster_s / 1e9 if raster_s > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": "k_raster", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
+                "algorithmic_bytes_per_launch": dem_bytes, "avg_launch_ms": round(kernel_ms["raster"], 4)}
+
+    out = {
+        "metric": "panorama Mpix/s",
+        "value": round(value, 2),
+        "unit": "Mpix/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"{args.workload}: {deg}x{deg} deg COP90-shaped mosaic ({n_tiles} tiles of 1200x1200 f32), "
+                               f"{PW}x{PH} panorama = 8 sectors of {SW}x{PH}, view_mode {args.view_mode}",
+                   "sharding": f"azimuth sectors, {per} per GPU, DEM replicated" + (", RCCL all-gather of RGBA" if world > 1 else "")},
+        "roofline": roofline,
+        "kernel_ms": {k: round(v, 4) for k, v in kernel_ms.items()},
+        "load_ms": round(load_ms, 4),
+        "load_GBps": round(8.0 * n_tiles * TILE * TILE / (load_ms / 1e3) / 1e9, 1) if load_ms > 0 else None,
+        "hbm_read_roofline_frac_frame": round((4.0 * n_tiles * TILE * TILE / (ms_per_step / 1e3) / 1e9) / HBM_PEAK_GBPS, 5),
+        "counters": counters,
+        "setup_s": round(setup_s, 1),
+        "upload_s": round(upload_s, 2),
+    }
+
+    # ---- CPU baseline: the oracle (a C++ port of the reference's shaders + raster semantics; the reference's
+    # own wgpu CPU-adapter path cannot be built here) on a bounded sample, rank 0 at N=1 only.
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(T, np, locs, vlat, vlon, views, SW, PH, args.cpu_threads)
+
+    if args.check and rank == 0:
+        out["check"] = check_against_oracle(T, np, locs, views, my, mine, depth, SW, PH)
+
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def _nearest_tiles(locs, vlat, vlon, k):
+    return sorted(locs, key=lambda l: (l[0] + 0.5 - vlat) ** 2 + (l[1] + 0.5 - vlon) ** 2)[:k]
+
+
+def cpu_baseline(T, np, locs, vlat, vlon, views, SW, PH, threads):
+    from oracle import oracle as O
+    cores = threads or min(N_SECTORS, os.cpu_count() or 1)
+    sample = _nearest_tiles(locs, vlat, vlon, min(9, len(locs)))
+    o = O.OracleRenderer(SW, PH)
+    for (la, lo) in [l for l in locs if l in sample]:          # keep the insertion order
+        o.add_terrain(la, lo, T.synth_tile(la, lo, TILE, TILE), *T.synth.tile_transform(la, lo, TILE, TILE))
+    o.update(SW, PH, views[0], T.post_uniforms(SW, PH))
+    t0 = time.perf_counter()
+    o.render_views(views, threads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": round(N_SECTORS * SW * PH / 1e6 / dt, 3), "unit": "Mpix/s", "cores": cores, "kind": "port",
+            "seconds": round(dt, 2),
+            "sample": f"all 8 sectors at full size ({N_SECTORS * SW}x{PH}) over the {len(sample)} tiles nearest the viewpoint "
+                      f"of {len(locs)} (the full mosaic has {len(locs) / len(sample):.1f}x the triangles); oracle/topo_oracle.cpp, "
+                      f"one OpenMP thread per sector"}
+
+
+def check_against_oracle(T, np, locs, views, my, mine, depth, SW, PH):
+    from oracle import oracle as O
+    o = O.OracleRenderer(SW, PH)
+    for (la, lo) in locs:
+        o.add_terrain(la, lo, T.synth_tile(la, lo, TILE, TILE), *T.synth.tile_transform(la, lo, TILE, TILE))
+    o.update(SW, PH, views[my[0]], T.post_uniforms(SW, PH))
+    ro, do = o.render()
+    rg, dg = mine[0].cpu().numpy(), depth[0].cpu().numpy()
+    return {"sector": my[0], "rgba_mismatch": int((ro != rg).any(axis=-1).sum()),
+            "depth_mismatch": int((do.view(np.uint32) != dg.view(np.uint32)).sum())}
+
+
+if __name__ == "__main__":
+    main()

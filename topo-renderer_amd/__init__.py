@@ -50,6 +50,21 @@ def build(verbose: bool = False) -> str:
 _lib = None
 
 
+def _preload_torch_hip_runtime():
+    """PyTorch wheels bundle their own libamdhip64.so (same SONAME as /opt/rocm's).  Two HIP runtimes in one
+    process cannot both own the GPU, so when torch is installed its runtime is loaded first and
+    libtopo_hip.so binds to it; processes that never import torch are unaffected."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec and spec.submodule_search_locations:
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def lib():
     """The loaded C ABI.  Fails loudly when the HIP extension has not been built."""
     global _lib
@@ -57,6 +72,7 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} is missing -- run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(there is no Python/CPU fallback for the render path)")
+        _preload_torch_hip_runtime()
         L = C.CDLL(LIB_PATH)
         vp, u32, i32, f32, sz = C.c_void_p, C.c_uint32, C.c_int32, C.c_float, C.c_size_t
         sigs = {
