@@ -98,7 +98,7 @@ def main():
 
     # ---- outputs: sector-major strip so each rank's share is contiguous for the all-gather
     per = N_SECTORS // world
-    my = list(range(rank * per, (rank + 1) * per))
+    my = list(T.panorama.sector_range(rank, world))
     strip = torch.empty((N_SECTORS, PH, SW, 4), dtype=torch.uint8, device="cuda")
     depth = torch.empty((per, PH, SW), dtype=torch.float32, device="cuda")
     mine = strip[my[0]:my[0] + per]
@@ -106,8 +106,7 @@ def main():
     def step():
         r.render_views_device([views[k] for k in my], SW, PH, mine.data_ptr(), PH * SW * 4, SW * 4,
                               depth.data_ptr(), PH * SW * 4, SW * 4)
-        if dist is not None:
-            dist.all_gather_into_tensor(strip.view(-1), mine.reshape(-1))
+        T.panorama.gather_strip(dist, strip, rank, world)
 
     def fence():
         if dist is not None:
@@ -197,7 +196,7 @@ def _nearest_tiles(locs, vlat, vlon, k):
 def cpu_baseline(T, np, locs, vlat, vlon, views, SW, PH, threads):
     from oracle import oracle as O
     cores = threads or min(N_SECTORS, os.cpu_count() or 1)
-    sample = _nearest_tiles(locs, vlat, vlon, min(9, len(locs)))
+    sample = _nearest_tiles(locs, vlat, vlon, len(locs) if os.environ.get('TOPO_CPU_SAMPLE_TILES') is None else int(os.environ['TOPO_CPU_SAMPLE_TILES']))
     o = O.OracleRenderer(SW, PH)
     for (la, lo) in [l for l in locs if l in sample]:          # keep the insertion order
         o.add_terrain(la, lo, T.synth_tile(la, lo, TILE, TILE), *T.synth.tile_transform(la, lo, TILE, TILE))
@@ -207,9 +206,8 @@ def cpu_baseline(T, np, locs, vlat, vlon, views, SW, PH, threads):
     dt = time.perf_counter() - t0
     return {"value": round(N_SECTORS * SW * PH / 1e6 / dt, 3), "unit": "Mpix/s", "cores": cores, "kind": "port",
             "seconds": round(dt, 2),
-            "sample": f"all 8 sectors at full size ({N_SECTORS * SW}x{PH}) over the {len(sample)} tiles nearest the viewpoint "
-                      f"of {len(locs)} (the full mosaic has {len(locs) / len(sample):.1f}x the triangles); oracle/topo_oracle.cpp, "
-                      f"one OpenMP thread per sector"}
+            "sample": f"one full panorama: all 8 sectors at full size ({N_SECTORS * SW}x{PH}) over {len(sample)} of the {len(locs)} tiles; "
+                      f"oracle/topo_oracle.cpp, one OpenMP thread per sector"}
 
 
 def check_against_oracle(T, np, locs, views, my, mine, depth, SW, PH):

@@ -158,3 +158,14 @@ class OracleRenderer:
         out = np.zeros(10, np.float32)
         lib().oracle_vs_main_probe(self._h, lat, lon, x, y, _p(out))
         return out
+
+
+def coverage_probe(W, H, tris):
+    """Accumulated coverage counts of triangles given in framebuffer pixels [(x0,y0,x1,y1,x2,y2), ...]."""
+    L = lib()
+    L.oracle_coverage_probe.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+    counts = np.zeros((H, W), np.uint32)
+    for t in tris:
+        xy = np.asarray(t, dtype=np.float32)
+        L.oracle_coverage_probe(W, H, _p(xy), _p(counts))
+    return counts

@@ -763,6 +763,33 @@ void oracle_geometry_transform(float h, float lon_deg, float lat_deg, float out[
 float oracle_dist_from_depth(float d) { return dist_from_depth(d); }
 uint32_t oracle_pad_256(uint32_t size) { return ((size - 1) / 256 + 1) * 256; } /* data/mod.rs:9-11 */
 
+/* Coverage probe for known-answer tests: rasterise ONE triangle given directly in framebuffer coordinates
+ * (pixels, f32) with z_ndc = z and w = 1 into a WxH target; out[p] = 1 + number of times pixel p was shaded
+ * minus 1, i.e. the count of fragments that passed coverage (depth test disabled by clearing between calls is
+ * the caller's business: counts accumulate across calls so shared edges can be checked for double hits). */
+void oracle_coverage_probe(uint32_t W, uint32_t H, const float xy[6], uint32_t* counts) {
+    ScreenVert s[3];
+    for (int k = 0; k < 3; ++k) {
+        s[k].X = (int64_t)rintf(xy[2 * k] * 256.0f);
+        s[k].Y = (int64_t)rintf(xy[2 * k + 1] * 256.0f);
+        s[k].z = 0.5f;
+        s[k].w = 1.0f;
+    }
+    Frame f;
+    f.W = W; f.H = H;
+    f.depth.assign((size_t)W * H, 1.0f);
+    f.color.assign((size_t)W * H * 4, 0);
+    Uniforms u;
+    memset(&u, 0, sizeof u);
+    u.view_mode = 2;
+    VSOut v;
+    memset(&v, 0, sizeof v);
+    v.clip[3] = 1.0f;
+    raster_triangle(f, u, v, v, v, s[0], s[1], s[2]);
+    for (size_t p = 0; p < (size_t)W * H; ++p)
+        if (f.depth[p] < 1.0f) counts[p] += 1;
+}
+
 /* math probes for cross-checking the product's device header */
 void oracle_sincos(const float* x, float* s, float* c, size_t n) {
     for (size_t i = 0; i < n; ++i) sincos_spec(x[i], &s[i], &c[i]);

@@ -161,6 +161,23 @@ int emul_render(const EmulTile* tiles, uint32_t n_tiles, uint32_t tile_w, uint32
     return 0;
 }
 
+// coverage of one triangle given in framebuffer pixels (same contract as oracle_coverage_probe)
+void emul_coverage_probe(uint32_t W, uint32_t H, const float xy[6], uint32_t* counts) {
+    SVert s[3];
+    for (int k = 0; k < 3; ++k) {
+        s[k].X = (int32_t)rintf(xy[2 * k] * 256.0f); s[k].Y = (int32_t)rintf(xy[2 * k + 1] * 256.0f);
+        s[k].z = 0.5f; s[k].flag = kVtxOk;
+    }
+    TriSetup ts;
+    if (!triangle_setup(s[0], s[1], s[2], (int32_t)W, (int32_t)H, ts)) return;
+    for (int py = ts.py0; py <= ts.py1; ++py) for (int px = ts.px0; px <= ts.px1; ++px) {
+        float z, b[3];
+        if (triangle_pixel(ts, px, py, z, b)) counts[(size_t)py * W + px] += 1;
+    }
+}
+
+uint64_t emul_vis_key(float z, uint32_t id) { return vis_key(z, id); }
+
 void emul_srgb_tables(float* decode, float* thresh) {
     for (int i = 0; i < 256; ++i) decode[i] = bits_f(TOPO_SRGB_DECODE_BITS[i]);
     for (int i = 0; i < 255; ++i) thresh[i] = bits_f(TOPO_SRGB_THRESH_BITS[i]);

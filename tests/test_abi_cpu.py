@@ -1,0 +1,109 @@
+"""The C-ABI library loads, exports every symbol include/topo_hip.h declares, refuses to work without a GPU,
+and its host-side helpers (the reference's CPU math) agree with the oracle's independent restatement."""
+import math
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+
+def declared_symbols(path):
+    text = re.sub(r"/\*.*?\*/", "", open(path).read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(topo_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported(topo):
+    decl = declared_symbols(topo.HEADER_PATH)
+    assert len(decl) >= 20
+    nm = subprocess.run(["nm", "-D", "--defined-only", topo.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (topo_[a-z0-9_]+)", nm))
+    missing = [s for s in decl if s not in exported]
+    assert not missing, missing
+    L = topo.lib()
+    for s in decl:
+        assert hasattr(L, s)
+    assert set(L._topo_symbols) == set(decl), set(L._topo_symbols) ^ set(decl)
+
+
+def test_library_contains_gfx950_code_object(topo):
+    out = subprocess.run(["strings", "-n", "6", topo.LIB_PATH], capture_output=True, text=True).stdout
+    assert "gfx950" in out
+    for k in ("k_raster", "k_resolve", "k_normals_interior", "k_cull", "k_raster_big", "k_clear"):
+        assert k in out, k
+
+
+def test_no_cpu_fallback_without_gpu(topo):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(topo.TopoError) as e:
+        topo.TerrainRenderer(64, 64)
+    assert e.value.code == topo.TOPO_ERR_HIP and "no CPU fallback" in str(e.value)
+
+
+def test_product_never_references_the_oracle(topo):
+    import os
+    root = os.path.dirname(topo.HEADER_PATH)
+    pkg = os.path.dirname(topo.LIB_PATH)
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hpp", ".cpp", ".hip")) or f == "Makefile":
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle/" not in src.replace("oracle/ ", "") or f in ("topo_math.h",), f
+                assert "liboracle" not in src and "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_struct_layouts_and_small_helpers(topo, orc):
+    assert topo.pad_256(1) == 256 and topo.pad_256(256) == 256 and topo.pad_256(257) == 512
+    assert topo.pad_256(4 * 2048) == 8192 and topo.pad_256(4 * 128) == 512
+    for n in (1, 255, 256, 257, 4 * 800, 4 * 2048):
+        assert topo.pad_256(n) == orc.pad_256(n)
+    for d in (0.0, 0.5, 0.9, 0.999, 1.0):
+        assert topo.dist_from_depth(d) == float(orc.lib().oracle_dist_from_depth(d))
+    assert topo.dist_from_depth(0.0) == 50.0 and topo.dist_from_depth(1.0) == 500000.0
+
+
+def test_host_camera_math_matches_oracle_restatement(topo, orc):
+    rng = np.random.default_rng(3)
+    for _ in range(200):
+        lat, lon = rng.uniform(-80, 80), rng.uniform(-179, 179)
+        h = rng.uniform(0, 4000)
+        a, b = topo.geometry_transform(h, lon, lat), orc.geometry_transform(h, lon, lat)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        args = (a, rng.uniform(-4, 4), rng.uniform(-1.5, 1.5), math.radians(rng.uniform(10, 160)), 2048.0, 4096.0, lon, lat, int(rng.integers(0, 3)))
+        u, v = topo.camera_uniforms(*args), orc.camera_uniforms(*args)
+        assert np.array_equal(u.view(np.uint32), v.view(np.uint32))
+        tu = (np.float32([0, 0]), np.float32([math.floor(lon), math.floor(lat) + 1]), np.float32([1 / 1200, 1 / 1200]), 1200, 1200)
+        assert np.array_equal(topo.terrain_uniforms(*tu).view(np.uint32), orc.terrain_uniforms(*tu).view(np.uint32))
+    # degenerate arcs of Quat::from_rotation_arc: eye on the -Y / +Y axis
+    for eye in ((0.0, -6.4e6, 0.0), (0.0, 6.4e6, 0.0)):
+        args = (np.float32(eye), 0.3, 0.1, 1.0, 800.0, 600.0, 0.0, 0.0, 0)
+        assert np.array_equal(topo.camera_uniforms(*args).view(np.uint32), orc.camera_uniforms(*args).view(np.uint32))
+
+
+def test_sun_at_zenith_and_rotation_semantics(topo):
+    # LightAngle{theta: lon, phi: lat}.to_vec3() is the local zenith (camera.rs:44-53, :91-94)
+    lon, lat = 15.217, 45.123
+    eye = topo.geometry_transform(1000.0, lon, lat)
+    u = topo.camera_uniforms(eye, 0.0, 0.0, 1.0, 100.0, 100.0, lon, lat, 0)
+    zen = eye / np.linalg.norm(eye)
+    assert np.abs(u[36:39] - zen).max() < 1e-6
+    tu = topo.terrain_uniforms(np.float32([0, 0]), np.float32([lon, lat]), np.float32([1 / 1200, 1 / 1200]), 1200, 1200)
+    rot = tu[8:24].reshape(4, 4).T[:3, :3]
+    assert np.abs(rot @ np.array([0, 0, 1.0]) - zen).max() < 1e-6      # normal-space +z -> zenith
+
+
+def test_synth_numpy_and_cpp_agree(topo):
+    for (la, lo, n) in ((45, 15, 64), (-3, -70, 33), (0, 0, 128), (49, 19, 1200)):
+        a = topo.synth_tile(la, lo, n, n)
+        b = topo.synth.synth_tile(la, lo, n, n)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        assert a.min() >= 0 and a.max() <= 3000
+    left, right = topo.synth_tile(45, 15, 64, 64), topo.synth_tile(45, 16, 64, 64)
+    assert np.abs(left[:, -1] - right[:, 0]).max() < 60       # continuous across the tile border
+
+
+def test_sector_fov(topo):
+    for sw, sh in ((128, 256), (512, 1024), (1024, 2048), (2048, 4096)):
+        assert abs(math.degrees(topo.sector_fov_y(sw, sh)) - 79.2785) < 1e-3

@@ -1,0 +1,81 @@
+"""N > 1 path on CPU: two gloo ranks each produce their azimuth sectors, all-gather the sector-major strip with
+the same helper bench.py uses, and must end up with the single-process panorama."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, expect_path, out_q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import topo_renderer_amd as T
+    from oracle import oracle as O
+    from scenes import Scene
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sc = Scene(24, 2, 2)
+        sw, sh = 16, 32
+        views = sc.panorama(sw, sh, yaw0_deg=5.0)
+        mine = T.panorama.sector_range(rank, world)
+        o = O.OracleRenderer(sw, sh)          # stand-in producer: the CPU suite has no GPU to render with
+        sc.load(o)
+        o.update(sw, sh, views[0], T.post_uniforms(sw, sh))
+        rgba, _ = o.render_views([views[k] for k in mine], threads=1)
+        strip = torch.zeros((8, sh, sw, 4), dtype=torch.uint8)
+        strip[mine.start:mine.stop] = torch.from_numpy(rgba)
+        T.panorama.gather_strip(dist, strip, rank, world)
+        expect = torch.from_numpy(np.load(expect_path))
+        out_q.put((rank, bool(torch.equal(strip, expect)), list(mine)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2])
+def test_sector_sharding_allgather_gloo(tmp_path, world):
+    sys.path.insert(0, ROOT)
+    import topo_renderer_amd as T
+    from oracle import oracle as O
+    from scenes import Scene
+    sc = Scene(24, 2, 2)
+    sw, sh = 16, 32
+    views = sc.panorama(sw, sh, yaw0_deg=5.0)
+    o = O.OracleRenderer(sw, sh)
+    sc.load(o)
+    o.update(sw, sh, views[0], T.post_uniforms(sw, sh))
+    full, _ = o.render_views(views, threads=2)
+    path = str(tmp_path / "expect.npy")
+    np.save(path, full)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, path, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res
+    assert sorted(s for _, _, ss in res for s in ss) == list(range(8))
+
+
+def test_sector_range_and_row_major(topo):
+    P = topo.panorama
+    assert [list(P.sector_range(r, 4)) for r in range(4)] == [[0, 1], [2, 3], [4, 5], [6, 7]]
+    assert list(P.sector_range(0, 1)) == list(range(8))
+    with pytest.raises(ValueError):
+        P.sector_range(0, 3)
+    strip = np.arange(8 * 2 * 3 * 4, dtype=np.int32).reshape(8, 2, 3, 4)
+    rm = P.to_row_major(strip)
+    assert rm.shape == (2, 24, 4)
+    for k in range(8):
+        assert np.array_equal(rm[:, 3 * k:3 * k + 3], strip[k])
+    assert torch.equal(P.to_row_major(torch.from_numpy(strip)), torch.from_numpy(rm))

@@ -1,0 +1,91 @@
+"""The product's device arithmetic (topo_math.h / topo_pipeline.h, the very headers the HIP kernels compile)
+executed on the CPU by tests/host_emul.cpp and compared bit for bit with the independently written oracle.
+This is what lets a CPU-only run vouch for the kernels' arithmetic; the GPU run (-m gpu) then only has to show
+that hipcc's code generation agrees with g++'s."""
+import math
+
+import numpy as np
+import pytest
+
+import emul
+from scenes import Scene, assert_same_frame
+
+
+def test_sincos_matches_oracle_and_libm(orc):
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.uniform(-3.3, 3.3, 300000), np.linspace(-10, 10, 100001), np.float32([0.0, -0.0, np.pi / 4, np.pi / 2, np.pi])]).astype(np.float32)
+    s, c = np.empty_like(x), np.empty_like(x)
+    emul.lib().emul_sincos(emul._p(x), emul._p(s), emul._p(c), x.size)
+    so, co = orc.sincos(x)
+    assert np.array_equal(s.view(np.uint32), so.view(np.uint32)) and np.array_equal(c.view(np.uint32), co.view(np.uint32))
+    x64 = x.astype(np.float64)
+    assert np.abs(s - np.sin(x64)).max() < 1.5e-7 and np.abs(c - np.cos(x64)).max() < 1.5e-7
+
+
+def test_vis_key_orders_like_less_then_draw_order():
+    L = emul.lib()
+    import ctypes as C
+    L.emul_vis_key.restype = C.c_uint64
+    L.emul_vis_key.argtypes = [C.c_float, C.c_uint32]
+    zs = np.float32([0.0, 1e-30, 0.25, 0.5, 0.99999994])
+    for i in range(len(zs) - 1):
+        assert L.emul_vis_key(zs[i], 0xFFFFFFFE) < L.emul_vis_key(zs[i + 1], 0)        # nearer always wins
+    assert L.emul_vis_key(0.5, 10) < L.emul_vis_key(0.5, 11)                            # equal depth: earlier draw wins
+    assert L.emul_vis_key(0.99999994, 0xFFFFFFFE) < 0x3F800000FFFFFFFF                  # anything < 1.0 beats the clear value
+
+
+def test_coverage_matches_oracle(orc):
+    import ctypes as C
+    L = emul.lib()
+    rng = np.random.default_rng(11)
+    W, H = 48, 40
+    for _ in range(300):
+        scale = rng.choice([3.0, 20.0, 200.0])
+        p = (rng.uniform(-0.3, 1.3, (3, 2)) * [W, H] * rng.uniform(0.2, 1.0) + rng.uniform(-scale, scale, 2)).astype(np.float32)
+        xy = np.ascontiguousarray(p.reshape(6))
+        a = orc.coverage_probe(W, H, [xy])
+        b = np.zeros((H, W), np.uint32)
+        L.emul_coverage_probe(W, H, emul._p(xy), emul._p(b))
+        assert np.array_equal(a, b)
+
+
+CASES = [
+    # tile, n_lat, n_lon, W, H, yaw, pitch, fov, mode, eye_dh
+    (64, 1, 1, 128, 64, 0, 0, 60, 0, 50),
+    (64, 1, 1, 128, 64, 0, 0, 60, 1, 50),
+    (64, 1, 1, 128, 64, 0, 0, 60, 2, 50),
+    (48, 3, 3, 160, 96, 200, 30, 79.28, 0, 50),
+    (64, 2, 2, 128, 128, 77, 60, 100, 0, 100),
+    (64, 2, 2, 128, 128, 77, 85, 100, 2, 400),
+    (100, 1, 2, 131, 67, 300, 20, 120, 0, 80),
+]
+
+
+@pytest.mark.parametrize("cfg", CASES, ids=[f"e{i}" for i in range(len(CASES))])
+def test_header_pipeline_matches_oracle(topo, orc, cfg):
+    tile, n_lat, n_lon, W, H, yaw, pitch, fov, mode, dh = cfg
+    sc = Scene(tile, n_lat, n_lon, eye_dh=dh)
+    e, o = emul.EmulRenderer(W, H, topo.terrain_uniforms), orc.OracleRenderer(W, H)
+    sc.load(e)
+    sc.load(o)
+    for loc in sc.locs:
+        assert np.array_equal(e.read_normals(*loc), o.read_normals(loc[0], loc[1], tile, tile))
+    u, pu = sc.uniforms(W, H, yaw, pitch, fov, mode), topo.post_uniforms(W, H)
+    e.update(W, H, u, pu)
+    o.update(W, H, u, pu)
+    assert_same_frame(e.render(), o.render(), f"emul {cfg}")
+
+
+def test_full_size_tile_matches_oracle(topo, orc):
+    # one real-size COP90 tile (1200x1200, 2.9 M triangles) into a 512x256 frame
+    sc = Scene(1200, 1, 1)
+    W, H = 512, 256
+    e, o = emul.EmulRenderer(W, H, topo.terrain_uniforms), orc.OracleRenderer(W, H)
+    sc.load(e)
+    sc.load(o)
+    u, pu = sc.uniforms(W, H, 140.0, 8.0, 79.2785, 0), topo.post_uniforms(W, H)
+    e.update(W, H, u, pu)
+    o.update(W, H, u, pu)
+    fe, fo = e.render(), o.render()
+    assert_same_frame(fe, fo, "1200x1200 tile")
+    assert 0.2 < float((fo[1] < 1).mean()) < 0.9

@@ -1,0 +1,237 @@
+"""Known-answer tests that pin the CPU oracle (the reference has no test on this path, so these
+are authored from its source text) and the committed golden vectors."""
+import hashlib
+import math
+import os
+
+import numpy as np
+import pytest
+
+from scenes import Scene
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+R0 = 6371000.0
+
+
+def flat(tile, h=1000.0):
+    return np.full((tile, tile), h, np.float32)
+
+
+def tr(topo, lat, lon, tile):
+    return topo.synth.tile_transform(lat, lon, tile, tile)
+
+
+def test_flat_tile_normals(topo, orc):
+    # (1) flat tile -> interior texel (128,128,255,0), border ring untouched (compute_normals_shader.wgsl:30-33)
+    o = orc.OracleRenderer(8, 8)
+    o.add_terrain(45, 15, flat(16), *tr(topo, 45, 15, 16))
+    n = o.read_normals(45, 15, 16, 16)
+    assert (n[1:-1, 1:-1] == np.array([128, 128, 255, 0], np.uint8)).all()
+    border = np.ones((16, 16), bool)
+    border[1:-1, 1:-1] = False
+    assert (n[border] == 0).all()
+
+
+def expected_normal(hT, hL, hR, hB, lat_deg, scale):
+    # closed form of compute_normals_shader.wgsl:35-45 in f64
+    x = math.radians(scale) * R0
+    y = math.radians(scale) * R0 * math.cos(math.radians(lat_deg))
+    n = np.array([-2 * y * (hR - hL), -2 * x * (hT - hB), 4 * x * y])
+    n /= np.linalg.norm(n)
+    return np.floor(np.clip(0.5 * (n + 1), 0, 1) * 255 + 0.5)
+
+
+def test_ramp_normals_closed_form(topo, orc):
+    # (2) planar east / north ramps
+    tile = 32
+    xs = np.arange(tile, dtype=np.float32)
+    east = np.tile(100.0 * xs, (tile, 1)).astype(np.float32)            # h grows eastwards
+    north = np.tile((100.0 * (tile - 1 - xs))[:, None], (1, tile)).astype(np.float32)   # h grows northwards (row 0 = north)
+    for hts, (dT_B, dR_L) in ((east, (0.0, 200.0)), (north, (200.0, 0.0))):
+        o = orc.OracleRenderer(8, 8)
+        o.add_terrain(45, 15, hts, *tr(topo, 45, 15, tile))
+        n = o.read_normals(45, 15, tile, tile)
+        for (yy, xx) in ((1, 1), (10, 20), (30, 30)):
+            lat = 46.0 - yy / tile
+            e = expected_normal(dT_B, 0.0, dR_L, 0.0, lat, 1.0 / tile)
+            assert np.abs(n[yy, xx, :3].astype(int) - e).max() <= 1, (yy, xx, n[yy, xx], e)
+            assert n[yy, xx, 3] == 0
+
+
+def test_seams_and_corner_write_pattern(topo, orc):
+    # (3) 2x2 block: which texels each seam / corner pass writes, and that the corner's `top` tap comes from the
+    # bottom-right tile (compute_normals_corner_shader.wgsl:49)
+    tile = 12
+    sc = Scene(tile, 2, 2)
+    o = orc.OracleRenderer(8, 8)
+    nw, ne, sw, se = sc.locs          # N->S, W->E insertion order
+    o.add_terrain(*nw, sc.heights[nw], *sc.transform(nw))
+    n = o.read_normals(*nw, tile, tile)
+    assert (n[:, -1] == 0).all() and (n[-1, :] == 0).all()
+    o.add_terrain(*ne, sc.heights[ne], *sc.transform(ne))
+    a, b = o.read_normals(*nw, tile, tile), o.read_normals(*ne, tile, tile)
+    assert (a[1:-1, -1, :3] != 0).any(axis=-1).all() and np.array_equal(a[1:-1, -1], b[1:-1, 0])   # shared seam normal
+    assert (a[0, -1] == 0).all() and (a[-1, -1] == 0).all()            # seam end points skipped (edge_shader.wgsl:33)
+    o.add_terrain(*sw, sc.heights[sw], *sc.transform(sw))
+    c = o.read_normals(*sw, tile, tile)
+    a = o.read_normals(*nw, tile, tile)
+    assert np.array_equal(a[-1, 1:-1], c[0, 1:-1]) and (a[-1, -1] == 0).all()
+    o.add_terrain(*se, sc.heights[se], *sc.transform(se))
+    a, b, c, d = (o.read_normals(*l, tile, tile) for l in (nw, ne, sw, se))
+    corner = a[-1, -1]
+    assert (corner[:3] != 0).any()
+    assert np.array_equal(corner, b[-1, 0]) and np.array_equal(corner, c[0, -1]) and np.array_equal(corner, d[0, 0])
+    H = sc.heights
+    hT = float(H[se][tile - 2, 0])       # `top` from terrain_heightmap_rb at (0, H-2)
+    hL = float(H[nw][tile - 1, tile - 2])
+    hR = float(H[ne][tile - 1, 1])
+    hB = float(H[sw][1, tile - 1])
+    lat_row = (se[0] + 1) - (tile - 1) / tile          # uniforms of the NEW tile (se), row H-1
+    e = expected_normal(hT, hL, hR, hB, lat_row, 1.0 / tile)
+    assert np.abs(corner[:3].astype(int) - e).max() <= 1
+
+
+def test_seam_depends_on_insertion_order(topo, orc):
+    # top/bottom seam latitude is row H-1 of whichever tile arrives last (terrain_renderer.rs:275)
+    tile = 10
+    sc = Scene(tile, 2, 1)
+    north, south = sc.locs
+    rows = 8000.0 * np.arange(2 * tile, dtype=np.float32)                 # one north-south ramp across both tiles
+    hts = {north: np.tile(rows[:tile, None], (1, tile)), south: np.tile(rows[tile:, None], (1, tile))}
+    res = []
+    for order in ((north, south), (south, north)):
+        o = orc.OracleRenderer(8, 8)
+        for loc in order:
+            o.add_terrain(*loc, hts[loc], *sc.transform(loc))
+        res.append(o.read_normals(*north, tile, tile)[-1, 1:-1].copy())
+        new = order[1]
+        lat_row = (new[0] + 1) - (tile - 1) / tile
+        e = expected_normal(float(rows[tile - 2]), 0.0, 0.0, float(rows[tile + 1]), lat_row, 1.0 / tile)
+        assert np.abs(res[-1][3, :3].astype(int) - e).max() <= 1
+    assert not np.array_equal(res[0], res[1])
+
+
+def test_projection_depth_and_dist_roundtrip(topo, orc):
+    # (4) a point on the view axis at distance d has depth f(d-n)/(d(f-n)); dist_from_depth inverts it
+    sc = Scene(16, 1, 1)
+    u = orc.camera_uniforms(sc.eye, 0.3, 0.1, math.radians(60), 640, 480, 15.0, 45.0, 0)
+    m = u[:16].astype(np.float64).reshape(4, 4).T          # column-major -> matrix
+    eye = sc.eye.astype(np.float64)
+    up = eye / np.linalg.norm(eye)
+    # direction = third row of the view rotation, negated; recover it from the matrix: clip.w = -z_view = dot(f, p - eye)
+    f = m[3, :3]
+    assert abs(np.linalg.norm(f) - 1) < 1e-5 and abs(f @ up) < 0.2
+    n, fa = 50.0, 500000.0
+    for d in (60.0, 1000.0, 40000.0, 400000.0):
+        p = np.append(eye + d * f, 1.0)
+        clip = m @ p
+        depth = clip[2] / clip[3]
+        assert abs(clip[3] - d) < 2.0                       # f32 matrix at 6.4e6 magnitude: metre-level noise
+        expect = fa * (clip[3] - n) / (clip[3] * (fa - n))
+        assert abs(depth - expect) < 2.0 * n / clip[3] ** 2 + 2e-6    # a metre of f32 matrix noise moves depth by n/d^2
+        assert abs(orc.lib().oracle_dist_from_depth(np.float32(expect)) - clip[3]) / clip[3] < 5e-3
+
+
+def test_yaw_turns_left_and_positive_pitch_looks_down(topo, orc):
+    sc = Scene(16, 1, 1)
+    eye = sc.eye.astype(np.float64)
+    up = eye / np.linalg.norm(eye)
+
+    def fwd(yaw, pitch):
+        u = orc.camera_uniforms(sc.eye, yaw, pitch, math.radians(60), 100, 100, 0, 0, 0)
+        return u[:16].astype(np.float64).reshape(4, 4).T[3, :3]
+    f0, f1 = fwd(0.0, 0.0), fwd(0.2, 0.0)
+    assert np.cross(f0, f1) @ up > 0                        # +yaw turns counter-clockwise seen from above (to the left)
+    assert fwd(0.0, 0.3) @ up < -0.25                       # +pitch looks down (rotation_arc maps -Y to up)
+    # panorama sectors therefore step by -45 degrees so that the strip reads left to right (clockwise)
+    us = topo.panorama_uniforms(sc.eye, 0.4, 64, 128, 0.0, 0.0)
+    fs = [u[:16].astype(np.float64).reshape(4, 4).T[3, :3] for u in us]
+    for k in range(8):
+        a, b = fs[k], fs[(k + 1) % 8]
+        assert np.cross(a, b) @ up < 0 and abs(math.degrees(math.acos(np.clip(a @ b, -1, 1))) - 45.0) < 1e-3
+
+
+def test_top_left_rule_watertight(topo, orc):
+    # (5) single-triangle coverage with the top-left rule: a quad split either way covers every pixel centre once
+    W = H = 16
+    quad = [(2.0, 2.0), (2.0, 12.0), (12.0, 12.0), (12.0, 2.0)]          # a, b(below), d, c -- screen CCW = a,b,d
+    a, b, d, c = quad
+    counts = orc.coverage_probe(W, H, [a + b + d, d + c + a])
+    inside = np.zeros((H, W), np.uint32)
+    inside[2:12, 2:12] = 1            # pixel centres 2.5..11.5; edges at 2.0 (owned: left/top) and 12.0 (not owned)
+    assert np.array_equal(counts, inside)
+    counts = orc.coverage_probe(W, H, [(2.5, 2.5, 2.5, 12.5, 12.5, 12.5), (12.5, 12.5, 12.5, 2.5, 2.5, 2.5)])
+    exp = np.zeros((H, W), np.uint32)
+    exp[2:12, 2:12] = 1               # centres exactly on the left/top edges are in, on the right/bottom edges out
+    assert np.array_equal(counts, exp)
+    assert orc.coverage_probe(W, H, [a + d + b]).sum() == 0             # clockwise on screen = back face, culled
+    rng = np.random.default_rng(7)
+    for _ in range(50):                # random fans around a shared vertex: no pixel hit twice, none lost
+        ctr = rng.uniform(4, 12, 2)
+        ang = np.sort(rng.uniform(0, 2 * math.pi, 7))
+        pts = [tuple(np.round((ctr + 6 * np.array([math.cos(t), -math.sin(t)])) * 256) / 256) for t in ang]   # CCW on screen (y down)
+        tris = [tuple(ctr) + pts[i] + pts[(i + 1) % 7] for i in range(7)]
+        tris = [(t[0], t[1], t[2], t[3], t[4], t[5]) for t in tris]
+        cnt = orc.coverage_probe(W, H, [tuple(np.float32(v) for v in t) for t in tris])
+        assert cnt.max() <= 1
+
+
+def test_sky_colour_and_contour(topo, orc):
+    # (7) sky = sRGB8(0, 0.71, 0.885) after encode -> decode -> encode; (8) contour 0 on constant depth, black at a step
+    def enc(l):
+        s = 12.92 * l if l <= 0.0031308 else 1.055 * l ** (1 / 2.4) - 0.055
+        return int(math.floor(s * 255 + 0.5))
+    sky = np.array([enc(0.0), enc(0.71), enc(0.885), 255], np.uint8)
+    sc = Scene(64, 1, 1)
+    o = orc.OracleRenderer(128, 64)
+    sc.load(o)
+    o.update(128, 64, sc.uniforms(128, 64, mode=1), topo.post_uniforms(128, 64))
+    rgba, depth, pre = o.render(want_pre_post=True)
+    assert (rgba[0, 0] == sky).all() and (rgba[depth == 1.0][:, 3] == 255).all()
+    is_sky = depth == 1.0
+    interior_sky = is_sky.copy()
+    interior_sky[1:, :] &= is_sky[:-1, :]; interior_sky[:-1, :] &= is_sky[1:, :]
+    interior_sky[:, 1:] &= is_sky[:, :-1]; interior_sky[:, :-1] &= is_sky[:, 1:]
+    interior_sky[[0, -1], :] = False; interior_sky[:, [0, -1]] = False
+    assert (rgba[interior_sky] == sky).all()
+    # first terrain row under the horizon: centre near, sky neighbours at 500 km -> contour/center << 0 -> unchanged;
+    # last sky row above terrain: centre = 500 km, neighbours near -> contour/center ~ 3/8.. -> black
+    col = 64
+    ys = np.where(~is_sky[:, col])[0]
+    y_top = ys.min()
+    assert (rgba[y_top - 1, col, :3] == 0).all() and rgba[y_top - 1, col, 3] == 255
+    assert np.array_equal(rgba[y_top + 3, col], pre[y_top + 3, col]) or (rgba[y_top + 3, col, :3] <= pre[y_top + 3, col, :3]).all()
+
+
+def test_srgb_tables_match_committed(topo, orc):
+    import emul
+    d, t = orc.srgb_tables()
+    L = emul.lib()
+    d2, t2 = np.empty(256, np.float32), np.empty(255, np.float32)
+    L.emul_srgb_tables(emul._p(d2), emul._p(t2))
+    assert np.array_equal(d.view(np.uint32), d2.view(np.uint32))
+    assert np.array_equal(t.view(np.uint32), t2.view(np.uint32))
+    assert (np.diff(t) > 0).all()
+    for c in range(256):
+        assert orc.lib().oracle_srgb_encode(d[c]) == c
+
+
+@pytest.mark.parametrize("name", ["single_64", "block2x2_24", "nearfield_16"])
+def test_oracle_reproduces_golden(topo, orc, name):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    tile, n_lat, n_lon, W, H, yaw, pitch, fov, dh = g["params"]
+    sc = Scene(int(tile), int(n_lat), int(n_lon), eye_dh=float(dh))
+    sha = hashlib.sha256(b"".join(sc.heights[l].tobytes() for l in sc.locs)).digest()
+    assert np.array_equal(np.frombuffer(sha, np.uint8), g["heights_sha"]), "synthetic heights changed"
+    o = orc.OracleRenderer(int(W), int(H))
+    sc.load(o)
+    for i, loc in enumerate(sc.locs):
+        assert np.array_equal(o.read_normals(loc[0], loc[1], int(tile), int(tile)), g[f"normals_{i}"])
+    for mode in (0, 1, 2):
+        u = sc.uniforms(int(W), int(H), float(yaw), float(pitch), float(fov), mode)
+        assert np.array_equal(u.view(np.uint32), g[f"uniforms_{mode}"].view(np.uint32)), "host camera math changed"
+        o.update(int(W), int(H), u, topo.post_uniforms(int(W), int(H)))
+        rgba, depth = o.render()
+        assert np.array_equal(rgba, g[f"rgba_{mode}"])
+        if mode == 0:
+            assert np.array_equal(depth.view(np.uint32), g["depth_bits"])

@@ -19,7 +19,7 @@ import subprocess
 
 import numpy as np
 
-from . import synth  # noqa: F401  (re-exported)
+from . import panorama, synth  # noqa: F401  (re-exported)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtopo_hip.so")
@@ -163,9 +163,11 @@ def sector_fov_y(sector_w: int, sector_h: int, n_sectors: int = N_SECTORS) -> fl
 
 def panorama_uniforms(eye, yaw0, sector_w, sector_h, sun_theta_deg, sun_phi_deg, view_mode=0,
                       n_sectors: int = N_SECTORS, pitch: float = 0.0):
-    """The n_sectors reference cameras of a 360-degree strip: sector k looks at yaw0 + k*(360/n) degrees."""
+    """The n_sectors reference cameras of a 360-degree strip.  The reference's yaw grows counter-clockwise seen
+    from above (Camera::direction, camera.rs:101-109), so sector k looks at yaw0 - k*(360/n) degrees: the strip then
+    reads left to right, each sector's right edge meeting the next one's left edge."""
     fov = sector_fov_y(sector_w, sector_h, n_sectors)
-    return [camera_uniforms(eye, yaw0 + k * (2.0 * math.pi / n_sectors), pitch, fov, sector_w, sector_h,
+    return [camera_uniforms(eye, yaw0 - k * (2.0 * math.pi / n_sectors), pitch, fov, sector_w, sector_h,
                             sun_theta_deg, sun_phi_deg, view_mode) for k in range(n_sectors)]
 
 
