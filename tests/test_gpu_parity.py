@@ -214,9 +214,11 @@ def test_big_triangle_queue_and_clipping_paths_are_exercised(topo, orc):
     g, o = both(topo, orc, W, H)
     sc.load(g)
     sc.load(o)
+    big = []
     for yaw, pitch in ((10, 35), (200, 80), (100, 5)):
         u, pu = sc.uniforms(W, H, yaw, pitch, 110, 0), topo.post_uniforms(W, H)
         g.update(W, H, u, pu)
         o.update(W, H, u, pu)
         assert_same_frame(g.render(), o.render(), f"coarse mesh yaw {yaw} pitch {pitch}")
-        assert g.counters()["big_items"] > 0
+        big.append(g.counters()["big_items"])
+    assert max(big) > 50, big
