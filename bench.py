@@ -116,7 +116,7 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    kernel_ms = {k: 0.0 for k in ("clear", "cull", "raster", "raster_big", "resolve", "total")}
+    kernel_ms = {k: 0.0 for k in ("clear", "cull", "raster", "raster_rare", "raster_big", "resolve", "total")}
     t_start = time.perf_counter()
     for _ in range(args.steps):
         step()

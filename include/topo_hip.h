@@ -116,13 +116,15 @@ int topo_synchronize(topo_ctx* ctx);
 int topo_set_normals_lds_rows(topo_ctx* ctx, int rows);
 
 /* Per-kernel durations (ms, HIP events on the context's stream) of the last topo_render* call:
- * [0] clear  [1] cull  [2] raster  [3] raster_big  [4] resolve+post  [5] total;
- * of the last topo_recompute_normals: [6] load phase.  Synchronises. */
+ * [0] clear  [1] cull  [2] raster  [3] raster_rare  [4] raster_big  [5] resolve+post  [6] total;
+ * of the last topo_recompute_normals: [7] load phase.  Synchronises. */
 #define TOPO_TIMING_SLOTS 8
 int topo_get_timings(topo_ctx* ctx, float out_ms[TOPO_TIMING_SLOTS]);
 
 /* Counters of the last topo_render* call: [0] blocks rastered, [1] big-triangle items, [2] status bits
- * (bit 0: big-triangle queue overflowed -- handled, slower), [3] blocks tested. */
+ * (bit 0: big-triangle queue overflowed -- handled in-lane, slower, still exact; bit 1: rare-triangle queue
+ * overflowed -- triangles dropped, frame invalid; topo_render returns TOPO_ERR_CAPACITY), [3] rare triangles
+ * (>= 64 px across or near-clipped). */
 int topo_get_counters(topo_ctx* ctx, uint32_t out[4]);
 
 /* Test accessor: the tile's Rgba8Unorm normal texture, w*h*4 bytes, host pointer. */

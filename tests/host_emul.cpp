@@ -153,8 +153,8 @@ int emul_render(const EmulTile* tiles, uint32_t n_tiles, uint32_t tile_w, uint32
         const uint32_t c8 = srgb_encode(thresh, lin[0]) | (srgb_encode(thresh, lin[1]) << 8) | (srgb_encode(thresh, lin[2]) << 16) |
                             (to_unorm8(lin[3]) << 24);
         float dn[8]; int k = 0;
-        for (int i = -1; i <= 1; ++i) for (int j = -1; j <= 1; ++j) { if (i == 0 && j == 0) continue; dn[k++] = vdepth(px + i, py + j); }
-        const uint32_t o = post_pixel(thresh, decode, c8, dc, dn);
+        for (int i = -1; i <= 1; ++i) for (int j = -1; j <= 1; ++j) { if (i == 0 && j == 0) continue; dn[k++] = linear_depth(vdepth(px + i, py + j)); }
+        const uint32_t o = post_pixel(thresh, decode, c8, linear_depth(dc), dn);
         memcpy(rgba + ((size_t)py * W + px) * 4, &o, 4);
         depth[(size_t)py * W + px] = dc;
     }

@@ -22,14 +22,14 @@ import numpy as np
 from . import panorama, synth  # noqa: F401  (re-exported)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtopo_hip.so")
+LIB_PATH = os.environ.get("TOPO_HIP_LIB") or os.path.join(_HERE, "libtopo_hip.so")   # TOPO_HIP_LIB: A/B builds
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "topo_hip.h")
 
 TOPO_OK = 0
 TOPO_ERR_INVALID, TOPO_ERR_UNSUPPORTED, TOPO_ERR_HIP, TOPO_ERR_NOT_FOUND, TOPO_ERR_CAPACITY = -1, -2, -3, -4, -5
 FORMAT_RGBA8_UNORM_SRGB = 1
 TIMING_SLOTS = 8
-TIMING_NAMES = ("clear", "cull", "raster", "raster_big", "resolve", "total", "load", "_")
+TIMING_NAMES = ("clear", "cull", "raster", "raster_rare", "raster_big", "resolve", "total", "load")
 
 NEAR, FAR = 50.0, 500000.0           # data/camera.rs:6-7
 N_SECTORS = 8                        # fixed panorama sector count
@@ -264,7 +264,7 @@ class TerrainRenderer:
     def counters(self) -> dict:
         out = np.zeros(4, np.uint32)
         self._check(lib().topo_get_counters(self._h, _p(out)))
-        return {"blocks_rastered": int(out[0]), "big_items": int(out[1]), "status": int(out[2]), "blocks_tested": int(out[3])}
+        return {"blocks_rastered": int(out[0]), "big_items": int(out[1]), "status": int(out[2]), "rare_items": int(out[3])}
 
     def read_normals(self, lat_deg, lon_deg) -> np.ndarray:
         w, h = self.tile_size

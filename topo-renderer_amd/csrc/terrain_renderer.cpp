@@ -48,7 +48,7 @@ int TerrainRenderer::create(TerrainRenderer** out, int device, uint32_t w, uint3
     r->H_ = h;
     e = hipSetDevice(device);
     if (e == hipSuccess) e = hipStreamCreate(&r->own_stream_);
-    for (int i = 0; i < 8 && e == hipSuccess; ++i) e = hipEventCreate(&r->ev_[i]);
+    for (int i = 0; i < kNumEvents && e == hipSuccess; ++i) e = hipEventCreate(&r->ev_[i]);
     if (e != hipSuccess) {
         *err = std::string("HIP initialisation failed: ") + hipGetErrorString(e);
         delete r;
@@ -67,7 +67,7 @@ TerrainRenderer::~TerrainRenderer() {
         (void)hipFree(kv.second.d_normals);
         (void)hipFree(kv.second.d_minmax);
     }
-    void* bufs[] = {d_tiles_, d_views_, d_vis_, d_work_, d_big_, d_counters_, d_out_rgba_, d_out_depth_};
+    void* bufs[] = {d_tiles_, d_views_, d_vis_, d_work_, d_big_, d_rare_, d_counters_, d_out_rgba_, d_out_depth_};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
     for (auto& e : ev_)
@@ -192,10 +192,10 @@ int TerrainRenderer::recompute_normals() {
     std::vector<Tile*> order;
     for (auto& kv : tiles_) order.push_back(&kv.second);
     std::sort(order.begin(), order.end(), [](Tile* a, Tile* b) { return a->seq < b->seq; });
-    TOPO_HIP_TRY(hipEventRecord(ev_[6], stream_));
+    TOPO_HIP_TRY(hipEventRecord(ev_[7], stream_));
     for (Tile* t : order) TOPO_HIP_TRY(hipMemsetAsync(t->d_normals, 0, (size_t)tile_w_ * tile_h_ * 4, stream_));
     for (Tile* t : order) normals_for(*t, false);
-    TOPO_HIP_TRY(hipEventRecord(ev_[7], stream_));
+    TOPO_HIP_TRY(hipEventRecord(ev_[8], stream_));
     load_timed_ = true;
     TOPO_HIP_TRY(hipGetLastError());
     return TOPO_OK;
@@ -237,12 +237,13 @@ int TerrainRenderer::render_views_device(uint32_t n, const topo_uniforms* views,
     const uint32_t bxc = n_tiles ? (tile_w_ - 1 + kBCX - 1) / kBCX : 0, byc = n_tiles ? (tile_h_ - 1 + kBCY - 1) / kBCY : 0;
     const size_t pixels = (size_t)n * w * h;
     const size_t work_cap = (size_t)n * n_tiles * bxc * byc;
-    const size_t big_cap = 1u << 22;
+    const size_t big_cap = 1u << 22, rare_cap = 1u << 22;
     if (work_cap >= (1ull << 32)) return fail(TOPO_ERR_CAPACITY, "too many raster blocks in one submission");
     if (int rc = ensure(&d_vis_, &cap_vis_, pixels * 8)) return rc;
     if (int rc = ensure(&d_views_, &cap_views_, n * sizeof(ViewDev))) return rc;
     if (int rc = ensure(&d_work_, &cap_work_, (work_cap ? work_cap : 1) * sizeof(WorkItem))) return rc;
     if (int rc = ensure(&d_big_, &cap_big_, big_cap * sizeof(BigItem))) return rc;
+    if (int rc = ensure(&d_rare_, &cap_rare_, rare_cap * sizeof(RareItem))) return rc;
     if (!d_counters_) {
         if (int rc = ensure(&d_counters_, &cap_counters_, 16 * sizeof(uint32_t))) return rc;
         TOPO_HIP_TRY(hipMemsetAsync(d_counters_, 0, 16 * sizeof(uint32_t), stream_));
@@ -266,6 +267,8 @@ int TerrainRenderer::render_views_device(uint32_t n, const topo_uniforms* views,
     p.work = (WorkItem*)d_work_;
     p.counters = (uint32_t*)d_counters_;
     p.big = (BigItem*)d_big_;
+    p.rare = (RareItem*)d_rare_;
+    p.rare_cap = (uint32_t)rare_cap;
     p.work_cap = (uint32_t)work_cap;
     p.big_cap = (uint32_t)big_cap;
     p.n_views = n;
@@ -286,10 +289,12 @@ int TerrainRenderer::render_views_device(uint32_t n, const topo_uniforms* views,
     TOPO_HIP_TRY(hipEventRecord(ev_[2], stream_));
     launch_raster(p, stream_);
     TOPO_HIP_TRY(hipEventRecord(ev_[3], stream_));
-    launch_raster_big(p, stream_);
+    launch_raster_rare(p, stream_);
     TOPO_HIP_TRY(hipEventRecord(ev_[4], stream_));
-    launch_resolve(p, out, stream_);
+    launch_raster_big(p, stream_);
     TOPO_HIP_TRY(hipEventRecord(ev_[5], stream_));
+    launch_resolve(p, out, stream_);
+    TOPO_HIP_TRY(hipEventRecord(ev_[6], stream_));
     frame_timed_ = true;
     TOPO_HIP_TRY(hipGetLastError());
     return TOPO_OK;
@@ -316,6 +321,9 @@ int TerrainRenderer::render(uint8_t* rgba, size_t rgba_pitch, float* depth, size
     TOPO_HIP_TRY(hipMemcpy2DAsync(rgba, rgba_pitch, d_out_rgba_, row, row, H_, hipMemcpyDeviceToHost, stream_));
     if (depth) TOPO_HIP_TRY(hipMemcpy2DAsync(depth, depth_pitch, d_out_depth_, row, row, H_, hipMemcpyDeviceToHost, stream_));
     TOPO_HIP_TRY(hipStreamSynchronize(stream_));
+    uint32_t status = 0;
+    TOPO_HIP_TRY(hipMemcpy(&status, (uint32_t*)d_counters_ + 2, sizeof status, hipMemcpyDeviceToHost));
+    if (status & kStatusRareOverflow) return fail(TOPO_ERR_CAPACITY, "rare-triangle queue overflowed: frame incomplete");
     return TOPO_OK;
 }
 
@@ -342,13 +350,13 @@ int TerrainRenderer::get_timings(float out[TOPO_TIMING_SLOTS]) {
     for (int i = 0; i < TOPO_TIMING_SLOTS; ++i) out[i] = 0.0f;
     if (int rc = bind_device()) return rc;
     if (frame_timed_) {
-        TOPO_HIP_TRY(hipEventSynchronize(ev_[5]));
-        for (int i = 0; i < 5; ++i) TOPO_HIP_TRY(hipEventElapsedTime(&out[i], ev_[i], ev_[i + 1]));
-        TOPO_HIP_TRY(hipEventElapsedTime(&out[5], ev_[0], ev_[5]));
+        TOPO_HIP_TRY(hipEventSynchronize(ev_[6]));
+        for (int i = 0; i < 6; ++i) TOPO_HIP_TRY(hipEventElapsedTime(&out[i], ev_[i], ev_[i + 1]));
+        TOPO_HIP_TRY(hipEventElapsedTime(&out[6], ev_[0], ev_[6]));
     }
     if (load_timed_) {
-        TOPO_HIP_TRY(hipEventSynchronize(ev_[7]));
-        TOPO_HIP_TRY(hipEventElapsedTime(&out[6], ev_[6], ev_[7]));
+        TOPO_HIP_TRY(hipEventSynchronize(ev_[8]));
+        TOPO_HIP_TRY(hipEventElapsedTime(&out[7], ev_[7], ev_[8]));
     }
     return TOPO_OK;
 }
@@ -358,8 +366,9 @@ int TerrainRenderer::get_counters(uint32_t out[4]) {
     if (!d_counters_) return TOPO_OK;
     if (int rc = bind_device()) return rc;
     TOPO_HIP_TRY(hipStreamSynchronize(stream_));
-    TOPO_HIP_TRY(hipMemcpy(out, d_counters_, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    out[3] = last_blocks_tested_;
+    uint32_t c[4];
+    TOPO_HIP_TRY(hipMemcpy(c, d_counters_, sizeof c, hipMemcpyDeviceToHost));
+    out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
     return TOPO_OK;
 }
 

@@ -79,7 +79,8 @@ class TerrainRenderer {
     int lds_rows_ = 16;
 
     hipStream_t own_stream_ = nullptr, stream_ = nullptr;
-    hipEvent_t ev_[8] = {};
+    static constexpr int kNumEvents = 9;
+    hipEvent_t ev_[kNumEvents] = {};
     bool frame_timed_ = false, load_timed_ = false;
 
     // grow-only device buffers
@@ -88,6 +89,7 @@ class TerrainRenderer {
     void* d_vis_ = nullptr;      size_t cap_vis_ = 0;
     void* d_work_ = nullptr;     size_t cap_work_ = 0;
     void* d_big_ = nullptr;      size_t cap_big_ = 0;
+    void* d_rare_ = nullptr;     size_t cap_rare_ = 0;
     void* d_counters_ = nullptr; size_t cap_counters_ = 0;
     void* d_out_rgba_ = nullptr; size_t cap_out_rgba_ = 0;
     void* d_out_depth_ = nullptr; size_t cap_out_depth_ = 0;

@@ -21,7 +21,14 @@ struct WorkItem {          // one (view, tile, block) that survived the frustum 
 struct BigItem {           // a triangle too large for the in-lane loop, restricted to one 64x64 px region
     uint32_t view;
     uint32_t id;           // draw << 1 | fan   (kNoTri = empty slot)
-    uint32_t rx, ry;       // region index (64 px units)
+    uint32_t region;       // ry << 16 | rx  (64 px units)
+    int32_t X[3], Y[3];    // the snapped vertices: the consumer re-runs the exact integer setup on them
+    float z[3];
+};
+
+struct RareItem {          // a triangle the lean raster kernel does not handle itself: >= 64 px across, or near-clipped
+    uint32_t view;
+    uint32_t draw;         // tile rank * tris_per_tile + triangle
 };
 
 struct FrameParams {
@@ -29,9 +36,10 @@ struct FrameParams {
     const ViewDev* views;      // n_views
     uint64_t* vis;             // n_views * W * H visibility keys: depth bits << 32 | id
     WorkItem* work;
-    uint32_t* counters;        // [0] work count, [1] big count, [2] status bits
+    uint32_t* counters;        // [0] work count, [1] big count, [2] status bits, [3] rare count
     BigItem* big;
-    uint32_t work_cap, big_cap;
+    RareItem* rare;
+    uint32_t work_cap, big_cap, rare_cap;
     uint32_t n_views, n_tiles;
     int32_t W, H;
     uint32_t tile_w, tile_h;
@@ -46,7 +54,8 @@ struct OutputParams {
     size_t depth_view_stride, depth_pitch; // bytes
 };
 
-constexpr uint32_t kStatusBigOverflow = 1u;
+constexpr uint32_t kStatusBigOverflow = 1u;    // big-triangle queue full: handled in-lane (slower, still exact)
+constexpr uint32_t kStatusRareOverflow = 2u;   // rare-triangle queue full: triangles were DROPPED -> the frame is invalid
 
 // load phase (add_terrain)
 void launch_block_minmax(const float* heights, float* minmax, uint32_t w, uint32_t h, hipStream_t s);
@@ -60,6 +69,7 @@ void launch_normals_corner(const TileDev& lt, const TileDev& rt, const TileDev& 
 void launch_clear(const FrameParams& p, hipStream_t s);
 void launch_cull(const FrameParams& p, hipStream_t s);
 void launch_raster(const FrameParams& p, hipStream_t s);
+void launch_raster_rare(const FrameParams& p, hipStream_t s);
 void launch_raster_big(const FrameParams& p, hipStream_t s);
 void launch_resolve(const FrameParams& p, const OutputParams& o, hipStream_t s);
 

@@ -142,7 +142,7 @@ __global__ void k_normals_corner(const float* __restrict__ h_lt, const float* __
 // ======================================================================================================
 
 __global__ __launch_bounds__(256) void k_clear(uint64_t* __restrict__ vis, size_t n, uint32_t* __restrict__ counters) {
-    if (blockIdx.x == 0 && threadIdx.x < 2) counters[threadIdx.x] = 0;   // work count, big count (status is sticky)
+    if (blockIdx.x == 0 && threadIdx.x < 4 && threadIdx.x != 2) counters[threadIdx.x] = 0;   // work/big/rare counts (status is sticky)
     const size_t stride = (size_t)gridDim.x * blockDim.x * 2;
     for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 2; i < n; i += stride) {
         if (i + 1 < n) {
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void k_cull(FrameParams P) {
 
 // ---- raster ------------------------------------------------------------------------------------------
 
-// Pixel loop shared by the in-lane path and the big-triangle path.
+// Pixel loop of the generic (int64) path.
 __device__ __forceinline__ void raster_box(const TriSetup& ts, uint64_t* __restrict__ vis, int32_t W, uint32_t id,
                                            int32_t px0, int32_t px1, int32_t py0, int32_t py1) {
     for (int32_t py = py0; py <= py1; ++py)
@@ -229,44 +229,105 @@ __device__ __forceinline__ void raster_box(const TriSetup& ts, uint64_t* __restr
         }
 }
 
-// A set-up triangle: rasterise in-lane when its pixel box is tiny, otherwise hand one BigItem per
-// overlapped 64x64 region to k_raster_big (falling back to the in-lane loop if the queue is full).
-__device__ void emit_triangle(const FrameParams& P, const TriSetup& ts, uint32_t view, uint32_t id) {
-    uint64_t* vis = P.vis + (size_t)view * P.W * P.H;
-    const int32_t nx = ts.px1 - ts.px0 + 1, ny = ts.py1 - ts.py0 + 1;
-    if (nx <= 4 && ny <= 4) {
-        raster_box(ts, vis, P.W, id, ts.px0, ts.px1, ts.py0, ts.py1);
-        return;
-    }
-    const int32_t rx0 = ts.px0 >> 6, rx1 = ts.px1 >> 6, ry0 = ts.py0 >> 6, ry1 = ts.py1 >> 6;
+// Hand a triangle whose pixel box is larger than 4x4 to k_raster_big: one BigItem per overlapped 64x64 px
+// region.  Returns false when the queue is full (the caller then rasterises in-lane).
+__device__ bool enqueue_big(const FrameParams& P, uint32_t view, uint32_t id, const SVert& s0, const SVert& s1, const SVert& s2,
+                            int32_t px0, int32_t px1, int32_t py0, int32_t py1) {
+    const int32_t rx0 = px0 >> 6, rx1 = px1 >> 6, ry0 = py0 >> 6, ry1 = py1 >> 6;
     const uint32_t n = (uint32_t)((rx1 - rx0 + 1) * (ry1 - ry0 + 1));
     const uint32_t base = atomicAdd(&P.counters[1], n);
+    BigItem it;
+    it.view = view;
+    it.id = id;
+    it.X[0] = s0.X; it.X[1] = s1.X; it.X[2] = s2.X;
+    it.Y[0] = s0.Y; it.Y[1] = s1.Y; it.Y[2] = s2.Y;
+    it.z[0] = s0.z; it.z[1] = s1.z; it.z[2] = s2.z;
     if (base >= P.big_cap || n > P.big_cap - base) {
         atomicOr(&P.counters[2], kStatusBigOverflow);
-        // neutralise whatever part of the reservation is inside the queue, then do the work here
-        for (uint32_t k = base; k < P.big_cap && k - base < n; ++k) P.big[k] = BigItem{0, kNoTri, 0, 0};
-        raster_box(ts, vis, P.W, id, ts.px0, ts.px1, ts.py0, ts.py1);
-        return;
+        // neutralise whatever part of the reservation lies inside the queue
+        it.id = kNoTri;
+        it.region = 0;
+        for (uint32_t k = base; k < P.big_cap && k - base < n; ++k) P.big[k] = it;
+        return false;
     }
     uint32_t k = base;
     for (int32_t ry = ry0; ry <= ry1; ++ry)
-        for (int32_t rx = rx0; rx <= rx1; ++rx) P.big[k++] = BigItem{view, id, (uint32_t)rx, (uint32_t)ry};
+        for (int32_t rx = rx0; rx <= rx1; ++rx) {
+            it.region = ((uint32_t)ry << 16) | (uint32_t)rx;
+            P.big[k++] = it;
+        }
+    return true;
 }
 
-// Triangle with one or two vertices behind the near plane: full-precision path through clip_near.
-__device__ void emit_clipped(const FrameParams& P, const TileDev& t, const ViewDev& view, uint32_t view_idx,
-                             uint32_t tri, uint32_t draw) {
-    for (uint32_t fan = 0; fan < 2; ++fan) {
-        ResolvedTri r;
-        if (resolve_triangle(t, P.tile_w, P.tile_h, view, P.W, P.H, tri, fan, r)) emit_triangle(P, r.ts, view_idx, (draw << 1) | fan);
+// Triangles the lean kernel does not handle go to k_raster_rare.
+__device__ __forceinline__ void enqueue_rare(const FrameParams& P, uint32_t view, uint32_t draw) {
+    const uint32_t slot = atomicAdd(&P.counters[3], 1u);
+    if (slot < P.rare_cap) P.rare[slot] = RareItem{view, draw};
+    else atomicOr(&P.counters[2], kStatusRareOverflow);
+}
+
+// The common case: a triangle whose three snapped vertices span < 64 px.  Everything fits int32 (|delta| < 2^14
+// so every product is < 2^28); the integers are the same ones triangle_setup/triangle_pixel compute in int64, so
+// coverage, barycentrics and depth are bit-identical.  Edge functions are stepped incrementally.
+__device__ __forceinline__ void raster_small(const FrameParams& P, uint64_t* __restrict__ vis, const SVert& s0, const SVert& s1,
+                                             const SVert& s2, uint32_t view, uint32_t id) {
+    const int32_t X0 = s0.X, Y0 = s0.Y, X1 = s1.X, Y1 = s1.Y, X2 = s2.X, Y2 = s2.Y;
+    const int32_t mnx = min(X0, min(X1, X2)), mxx = max(X0, max(X1, X2));
+    const int32_t mny = min(Y0, min(Y1, Y2)), mxy = max(Y0, max(Y1, Y2));
+    if ((mxx - mnx) >= (1 << 14) || (mxy - mny) >= (1 << 14)) {
+        enqueue_rare(P, view, id >> 1);
+        return;
+    }
+    const int32_t area2 = (X1 - X0) * (Y2 - Y0) - (Y1 - Y0) * (X2 - X0);
+    if (area2 >= 0) return;
+    int32_t px0 = (mnx + 127) >> 8, px1 = (mxx - 128) >> 8, py0 = (mny + 127) >> 8, py1 = (mxy - 128) >> 8;
+    px0 = max(px0, 0);
+    py0 = max(py0, 0);
+    px1 = min(px1, P.W - 1);
+    py1 = min(py1, P.H - 1);
+    if (px0 > px1 || py0 > py1) return;
+    if (px1 - px0 >= 4 || py1 - py0 >= 4) {
+        if (!enqueue_big(P, view, id, s0, s1, s2, px0, px1, py0, py1)) enqueue_rare(P, view, id >> 1);
+        return;
+    }
+    // edges e0 = v1->v2, e1 = v2->v0, e2 = v0->v1
+    const int32_t dx0 = X2 - X1, dy0 = Y2 - Y1, dx1 = X0 - X2, dy1 = Y0 - Y2, dx2 = X1 - X0, dy2 = Y1 - Y0;
+    const int32_t b0 = ((dy0 > 0) || (dy0 == 0 && dx0 < 0)) ? 0 : -1;
+    const int32_t b1 = ((dy1 > 0) || (dy1 == 0 && dx1 < 0)) ? 0 : -1;
+    const int32_t b2 = ((dy2 > 0) || (dy2 == 0 && dx2 < 0)) ? 0 : -1;
+    const int32_t cx = px0 * 256 + 128, cy = py0 * 256 + 128;
+    int32_t r0 = dy0 * (cx - X1) - dx0 * (cy - Y1);
+    int32_t r1 = dy1 * (cx - X2) - dx1 * (cy - Y2);
+    int32_t r2 = dy2 * (cx - X0) - dx2 * (cy - Y0);
+    const float fA = (float)(-area2);
+    const float z0 = s0.z, dz1 = s1.z - s0.z, dz2 = s2.z - s0.z;
+    for (int32_t py = py0; py <= py1; ++py) {
+        int32_t F0 = r0, F1 = r1, F2 = r2;
+        for (int32_t px = px0; px <= px1; ++px) {
+            if (((F0 + b0) | (F1 + b1) | (F2 + b2)) >= 0) {
+                const float w1 = (float)F1 / fA, w2 = (float)F2 / fA;
+                float z = z0 + (w1 * dz1 + w2 * dz2);
+                if (z < 1.0f) {
+                    if (z < 0.0f) z = 0.0f;
+                    vis_min(vis + (size_t)py * P.W + px, vis_key(z, id));
+                }
+            }
+            F0 += dy0 * 256;
+            F1 += dy1 * 256;
+            F2 += dy2 * 256;
+        }
+        r0 -= dx0 * 256;
+        r1 -= dx1 * 256;
+        r2 -= dx2 * 256;
     }
 }
 
 // One workgroup per surviving (view, tile, block): stage the block's post-transform vertices in LDS
-// (each vertex transformed once: coalesced 244-B row reads of the DEM), then one lane per grid cell sets
-// up and rasterises its two triangles.
+// (each vertex transformed once from coalesced 244-B row reads of the DEM; sin/cos once per row and column),
+// then one lane per grid cell sets up and rasterises its two triangles.
 __global__ __launch_bounds__(256) void k_raster(FrameParams P) {
     __shared__ SVert sv[kVY][kVX];
+    __shared__ float2 s_lat[kVY], s_lon[kVX];      // (sin, cos)
     uint32_t count = P.counters[0];
     if (count > P.work_cap) count = P.work_cap;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -277,16 +338,30 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams P) {
         const ViewDev& view = P.views[view_idx];
         const uint32_t bx = wi.block % P.bx_count, by = wi.block / P.bx_count;
         const uint32_t x0 = bx * kBCX, y0 = by * kBCY;
+        // ---- phase 0: sin/cos of the block's rows and columns
+        if (threadIdx.x < kVX) {
+            float sn, cs;
+            sincos_f(vertex_lon(t, x0 + threadIdx.x), sn, cs);
+            s_lon[threadIdx.x] = make_float2(sn, cs);
+        } else if (threadIdx.x >= 64 && threadIdx.x < 64 + kVY) {
+            float sn, cs;
+            sincos_f(vertex_lat(t, y0 + threadIdx.x - 64), sn, cs);
+            s_lat[threadIdx.x - 64] = make_float2(sn, cs);
+        }
+        __syncthreads();
         // ---- phase 1: vertices
         if (lane < kVX) {
             const uint32_t vx = x0 + lane;
+            const float2 lo = s_lon[lane];
             for (uint32_t r = wave; r < kVY; r += 4) {
                 const uint32_t vy = y0 + r;
                 SVert s;
                 s.X = 0; s.Y = 0; s.z = 0.0f; s.flag = kVtxNear;
                 if (vx < P.tile_w && vy < P.tile_h) {
+                    const float2 la = s_lat[r];
+                    const f3 p = world_from_sincos(t.heights[(size_t)vy * P.tile_w + vx], la.x, la.y, lo.x, lo.y);
                     float clip[4];
-                    vertex_clip(t, view, vx, vy, t.heights[(size_t)vy * P.tile_w + vx], clip);
+                    mat4_point(view.proj, p.x, p.y, p.z, clip);
                     clip_to_screen(clip, (float)P.W, (float)P.H, s);
                 }
                 sv[r][lane] = s;
@@ -294,6 +369,7 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams P) {
         }
         __syncthreads();
         // ---- phase 2: cells
+        uint64_t* vis = P.vis + (size_t)view_idx * P.W * P.H;
         const uint32_t ncx = min(kBCX, P.tile_w - 1 - x0), ncy = min(kBCY, P.tile_h - 1 - y0);
         for (uint32_t c = threadIdx.x; c < ncx * ncy; c += 256) {
             const uint32_t cy = c / ncx, cx = c - cy * ncx;
@@ -308,25 +384,43 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams P) {
                 const SVert& s2 = k == 0 ? (even ? d : cc) : (even ? a : b);
                 const uint32_t tri = tri0 + k;
                 const uint32_t draw = rank * P.tris_per_tile + tri;
-                const int nnear = (s0.flag == kVtxNear) + (s1.flag == kVtxNear) + (s2.flag == kVtxNear);
-                if (nnear == 3) continue;
-                if (nnear != 0) {
-                    emit_clipped(P, t, view, view_idx, tri, draw);
-                    continue;
-                }
-                if ((s0.flag | s1.flag | s2.flag) != kVtxOk) continue;   // guard band: primitive discarded
-                TriSetup ts;
-                if (!triangle_setup(s0, s1, s2, P.W, P.H, ts)) continue;
-                emit_triangle(P, ts, view_idx, draw << 1);
+                const int fl = s0.flag | s1.flag | s2.flag;
+                if (fl == kVtxOk) {
+                    raster_small(P, vis, s0, s1, s2, view_idx, draw << 1);
+                } else if (fl & kVtxNear) {
+                    const int nnear = (s0.flag == kVtxNear) + (s1.flag == kVtxNear) + (s2.flag == kVtxNear);
+                    if (nnear != 3) enqueue_rare(P, view_idx, draw);
+                }   // else: guard band -> primitive discarded
             }
         }
         __syncthreads();
     }
 }
 
-// One wave per BigItem: all lanes rebuild the triangle (identical arithmetic, so identical bits), then
-// sweep the 8x8 sub-chunks of the item's 64x64 region that intersect the triangle's pixel box, one pixel
-// per lane.
+// One lane per RareItem: the generic exact path (near clipping, int64 setup).  Boxes up to 4x4 px are
+// rasterised in-lane, larger ones go to the big queue (or, if that is full, are rasterised here as well).
+__global__ __launch_bounds__(256) void k_raster_rare(FrameParams P) {
+    uint32_t count = P.counters[3];
+    if (count > P.rare_cap) count = P.rare_cap;
+    for (uint32_t item = blockIdx.x * blockDim.x + threadIdx.x; item < count; item += gridDim.x * blockDim.x) {
+        const RareItem ri = P.rare[item];
+        const uint32_t rank = ri.draw / P.tris_per_tile, tri = ri.draw - rank * P.tris_per_tile;
+        uint64_t* vis = P.vis + (size_t)ri.view * P.W * P.H;
+        for (uint32_t fan = 0; fan < 2; ++fan) {
+            ResolvedTri r;
+            if (!resolve_triangle(P.tiles[rank], P.tile_w, P.tile_h, P.views[ri.view], P.W, P.H, tri, fan, r)) continue;
+            const TriSetup& ts = r.ts;
+            const uint32_t id = (ri.draw << 1) | fan;
+            const int32_t nx = ts.px1 - ts.px0 + 1, ny = ts.py1 - ts.py0 + 1;
+            if ((nx <= 4 && ny <= 4) || !enqueue_big(P, ri.view, id, r.s[0], r.s[1], r.s[2], ts.px0, ts.px1, ts.py0, ts.py1))
+                raster_box(ts, vis, P.W, id, ts.px0, ts.px1, ts.py0, ts.py1);
+        }
+    }
+}
+
+// One wave per BigItem: the item carries the snapped vertices, so every lane re-runs the exact integer setup
+// (wave-uniform) and the wave sweeps the 8x8 px sub-chunks of the item's 64x64 region that intersect the
+// triangle's pixel box, one pixel per lane.
 __global__ __launch_bounds__(256) void k_raster_big(FrameParams P) {
     uint32_t count = P.counters[1];
     if (count > P.big_cap) count = P.big_cap;
@@ -335,20 +429,22 @@ __global__ __launch_bounds__(256) void k_raster_big(FrameParams P) {
     for (uint32_t item = wave_global; item < count; item += wave_count) {
         const BigItem bi = P.big[item];
         if (bi.id == kNoTri) continue;
-        const uint32_t draw = bi.id >> 1, fan = bi.id & 1u;
-        const uint32_t rank = draw / P.tris_per_tile, tri = draw - rank * P.tris_per_tile;
-        ResolvedTri r;
-        if (!resolve_triangle(P.tiles[rank], P.tile_w, P.tile_h, P.views[bi.view], P.W, P.H, tri, fan, r)) continue;
+        SVert s[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { s[k].X = bi.X[k]; s[k].Y = bi.Y[k]; s[k].z = bi.z[k]; s[k].flag = kVtxOk; }
+        TriSetup ts;
+        if (!triangle_setup(s[0], s[1], s[2], P.W, P.H, ts)) continue;
         uint64_t* vis = P.vis + (size_t)bi.view * P.W * P.H;
-        const int32_t bx0 = max(r.ts.px0, (int32_t)bi.rx * 64), bx1 = min(r.ts.px1, (int32_t)bi.rx * 64 + 63);
-        const int32_t by0 = max(r.ts.py0, (int32_t)bi.ry * 64), by1 = min(r.ts.py1, (int32_t)bi.ry * 64 + 63);
+        const int32_t rx = (int32_t)(bi.region & 0xFFFFu), ry = (int32_t)(bi.region >> 16);
+        const int32_t bx0 = max(ts.px0, rx * 64), bx1 = min(ts.px1, rx * 64 + 63);
+        const int32_t by0 = max(ts.py0, ry * 64), by1 = min(ts.py1, ry * 64 + 63);
         const int32_t lx = (int32_t)(lane & 7), ly = (int32_t)(lane >> 3);
         for (int32_t sy = by0 & ~7; sy <= by1; sy += 8)
             for (int32_t sx = bx0 & ~7; sx <= bx1; sx += 8) {
                 const int32_t px = sx + lx, py = sy + ly;
                 if (px < bx0 || px > bx1 || py < by0 || py > by1) continue;
                 float z, b[3];
-                if (triangle_pixel(r.ts, px, py, z, b)) vis_min(vis + (size_t)py * P.W + px, vis_key(z, bi.id));
+                if (triangle_pixel(ts, px, py, z, b)) vis_min(vis + (size_t)py * P.W + px, vis_key(z, bi.id));
             }
     }
 }
@@ -363,13 +459,20 @@ __device__ __forceinline__ float vis_depth(const uint64_t* vis, int32_t W, int32
 __global__ __launch_bounds__(256) void k_resolve(FrameParams P, OutputParams O) {
     __shared__ float s_thresh[256];
     __shared__ float s_decode[256];
+    __shared__ float s_lin[6][66];     // linear depth of the 64x4 pixel block + 1 px halo (clamp-to-edge)
     s_thresh[threadIdx.x] = bits_f(TOPO_SRGB_THRESH_BITS[threadIdx.x]);
     s_decode[threadIdx.x] = bits_f(TOPO_SRGB_DECODE_BITS[threadIdx.x]);
-    __syncthreads();
     const uint32_t view_idx = blockIdx.z;
-    const int32_t px = blockIdx.x * 64 + (threadIdx.x & 63), py = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (px >= P.W || py >= P.H) return;
     const uint64_t* vis = P.vis + (size_t)view_idx * P.W * P.H;
+    const int32_t bx = blockIdx.x * 64, by = blockIdx.y * 4;
+    for (int idx = threadIdx.x; idx < 6 * 66; idx += 256) {
+        const int ly = idx / 66, lx = idx - ly * 66;
+        s_lin[ly][lx] = linear_depth(vis_depth(vis, P.W, P.H, bx + lx - 1, by + ly - 1));
+    }
+    __syncthreads();
+    const int32_t tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int32_t px = bx + tx, py = by + ty;
+    if (px >= P.W || py >= P.H) return;
     const ViewDev& view = P.views[view_idx];
     const uint64_t key = vis[(size_t)py * P.W + px];
     const float depth = bits_f((uint32_t)(key >> 32));
@@ -391,16 +494,16 @@ __global__ __launch_bounds__(256) void k_resolve(FrameParams P, OutputParams O) 
     }
     const uint32_t c8 = srgb_encode(s_thresh, lin[0]) | (srgb_encode(s_thresh, lin[1]) << 8) |
                         (srgb_encode(s_thresh, lin[2]) << 16) | (to_unorm8(lin[3]) << 24);
-    float dn[8];
+    float ln[8];
     int k = 0;
 #pragma unroll
     for (int i = -1; i <= 1; ++i)
 #pragma unroll
         for (int j = -1; j <= 1; ++j) {
             if (i == 0 && j == 0) continue;
-            dn[k++] = vis_depth(vis, P.W, P.H, px + i, py + j);
+            ln[k++] = s_lin[ty + 1 + j][tx + 1 + i];
         }
-    const uint32_t out = post_pixel(s_thresh, s_decode, c8, depth, dn);
+    const uint32_t out = post_pixel(s_thresh, s_decode, c8, s_lin[ty + 1][tx + 1], ln);
     *reinterpret_cast<uint32_t*>(O.rgba + (size_t)view_idx * O.rgba_view_stride + (size_t)py * O.rgba_pitch + (size_t)px * 4) = out;
     if (O.depth)
         *reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(O.depth) + (size_t)view_idx * O.depth_view_stride +
@@ -465,6 +568,11 @@ void launch_cull(const FrameParams& p, hipStream_t s) {
 void launch_raster(const FrameParams& p, hipStream_t s) {
     if (p.n_tiles == 0) return;
     hipLaunchKernelGGL(k_raster, dim3(256 * 8), dim3(256), 0, s, p);
+}
+
+void launch_raster_rare(const FrameParams& p, hipStream_t s) {
+    if (p.n_tiles == 0) return;
+    hipLaunchKernelGGL(k_raster_rare, dim3(256), dim3(256), 0, s, p);
 }
 
 void launch_raster_big(const FrameParams& p, hipStream_t s) {

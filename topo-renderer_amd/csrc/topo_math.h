@@ -115,8 +115,10 @@ TOPO_HD float linear_depth(float d) { return kFar * kNear / (kFar - d * (kFar - 
 
 // ---- sRGB ----------------------------------------------------------------------------------------
 // `thresh` points at 256 floats (TOPO_SRGB_THRESH_BITS reinterpreted; entry 255 = +inf), `decode` at 256.
-// encode = number of thresholds <= l; 8 fixed probes, branch free.
+// encode = number of thresholds <= l.
 TOPO_HD uint32_t srgb_encode(const float* thresh, float l) {
+    // 8 fixed, independent-of-data probes.  (A "fast estimate + walk" variant measured 1.5x SLOWER inside
+    // k_resolve: divergent loops of dependent LDS loads; see profiles/README.md.)
     uint32_t lo = 0;
 #pragma unroll
     for (uint32_t step = 128; step >= 1; step >>= 1) {
@@ -177,15 +179,20 @@ TOPO_HD void shade_fragment(int view_mode, f3 sun, float cam_x, float cam_y, flo
 }
 
 // ---- post pass (postprocessing_shader.wgsl:68-96) -------------------------------------------------
-// `c8` = the render-target texel (sRGB8 rgb + unorm8 alpha), dc = centre depth, dn = the 8 neighbour
-// depths in the shader's loop order (i outer = x offset -1..1, j inner = y offset -1..1, centre skipped).
-TOPO_HD uint32_t post_pixel(const float* thresh, const float* decode, uint32_t c8, float dc, const float dn[8]) {
-    const float center = linear_depth(dc);
+// `c8` = the render-target texel (sRGB8 rgb + unorm8 alpha); taps in the shader's loop order (i outer = x
+// offset -1..1, j inner = y offset -1..1, centre skipped).
+TOPO_HD uint32_t post_pixel(const float* thresh, const float* decode, uint32_t c8, float center, const float ln[8]) {
+    // center / ln[] are ALREADY linear_depth() of the depth taps (each is a pure function of its texel, so a
+    // kernel may compute it once per texel and share it between the up to nine pixels that tap it).
     float contour = 8.0f * center;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) contour -= linear_depth(dn[k]);
+    for (int k = 0; k < 8; ++k) contour -= ln[k];
     float t = sat((contour / center - 0.05f) / (0.15f - 0.05f));
     const float a = t * t * (3.0f - 2.0f * t);
+    // mix(x, 0, 0) = x*1 + 0*0 = x and the decode->encode round trip of a code is the identity (checked when the
+    // tables are generated), alpha stays 255; mix(x, 0, 1) = x*0 + 0*1 = 0: both ends skip the table work.
+    if (a == 0.0f && (c8 >> 24) == 255u) return c8;
+    if (a == 1.0f && (c8 >> 24) == 255u) return 0xFF000000u;
     const float r = decode[c8 & 255u] * (1.0f - a) + 0.0f * a;
     const float g = decode[(c8 >> 8) & 255u] * (1.0f - a) + 0.0f * a;
     const float b = decode[(c8 >> 16) & 255u] * (1.0f - a) + 0.0f * a;

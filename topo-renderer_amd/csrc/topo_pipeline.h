@@ -48,15 +48,19 @@ struct VFull {                   // full vs_main output
 };
 
 // ---- vertex stage: render_shader.wgsl:35-73 --------------------------------------------------------
-TOPO_HD f3 vertex_world(const TileDev& t, uint32_t vx, uint32_t vy, float height) {
-    const float mx = ((float)vx - t.raster_x) * t.scale_x + t.model_x;
-    const float my = ((float)vy - t.raster_y) * -t.scale_y + t.model_y;
-    const float lon = deg2rad(mx), lat = deg2rad(my);
+// to_model + radians: longitude depends only on the vertex column, latitude only on its row, so a raster
+// block evaluates each sin/cos once per row/column (same function of the same input -> same bits).
+TOPO_HD float vertex_lon(const TileDev& t, uint32_t vx) { return deg2rad(((float)vx - t.raster_x) * t.scale_x + t.model_x); }
+TOPO_HD float vertex_lat(const TileDev& t, uint32_t vy) { return deg2rad(((float)vy - t.raster_y) * -t.scale_y + t.model_y); }
+TOPO_HD f3 world_from_sincos(float height, float sla, float cla, float slo, float clo) {
     const float R = kR0 + height;
-    float sla, cla, slo, clo;
-    sincos_f(lat, sla, cla);
-    sincos_f(lon, slo, clo);
     return {R * cla * clo, R * cla * slo, R * sla};
+}
+TOPO_HD f3 vertex_world(const TileDev& t, uint32_t vx, uint32_t vy, float height) {
+    float sla, cla, slo, clo;
+    sincos_f(vertex_lat(t, vy), sla, cla);
+    sincos_f(vertex_lon(t, vx), slo, clo);
+    return world_from_sincos(height, sla, cla, slo, clo);
 }
 
 TOPO_HD f3 vertex_normal(const TileDev& t, uint32_t packed) {
@@ -252,6 +256,7 @@ TOPO_HD void vertex_clip(const TileDev& t, const ViewDev& v, uint32_t vx, uint32
 // pixel evaluation.  Returns false if it does not exist / is culled (cannot happen for an id that won a pixel).
 struct ResolvedTri {
     VFull v[3];
+    SVert s[3];
     TriSetup ts;
 };
 TOPO_HD bool resolve_triangle(const TileDev& t, uint32_t tile_w, uint32_t tile_h, const ViewDev& view, int32_t W,
@@ -264,11 +269,10 @@ TOPO_HD bool resolve_triangle(const TileDev& t, uint32_t tile_w, uint32_t tile_h
     const bool all_in = r.v[0].clip[2] >= 0.0f && r.v[1].clip[2] >= 0.0f && r.v[2].clip[2] >= 0.0f;
     if (all_in) {   // the common case, kept free of runtime-indexed arrays
         if (fan != 0) return false;
-        SVert s0, s1, s2;
-        if (clip_to_screen(r.v[0].clip, (float)W, (float)H, s0) != kVtxOk) return false;
-        if (clip_to_screen(r.v[1].clip, (float)W, (float)H, s1) != kVtxOk) return false;
-        if (clip_to_screen(r.v[2].clip, (float)W, (float)H, s2) != kVtxOk) return false;
-        return triangle_setup(s0, s1, s2, W, H, r.ts);
+        if (clip_to_screen(r.v[0].clip, (float)W, (float)H, r.s[0]) != kVtxOk) return false;
+        if (clip_to_screen(r.v[1].clip, (float)W, (float)H, r.s[1]) != kVtxOk) return false;
+        if (clip_to_screen(r.v[2].clip, (float)W, (float)H, r.s[2]) != kVtxOk) return false;
+        return triangle_setup(r.s[0], r.s[1], r.s[2], W, H, r.ts);
     }
     VFull poly[4];
     const int n = clip_near(r.v, poly);
@@ -277,7 +281,8 @@ TOPO_HD bool resolve_triangle(const TileDev& t, uint32_t tile_w, uint32_t tile_h
     for (int k = 0; k < n; ++k)
         if (clip_to_screen(poly[k].clip, (float)W, (float)H, s[k]) != kVtxOk) return false;
     r.v[0] = poly[0]; r.v[1] = poly[fan + 1]; r.v[2] = poly[fan + 2];
-    return triangle_setup(s[0], s[fan + 1], s[fan + 2], W, H, r.ts);
+    r.s[0] = s[0]; r.s[1] = s[fan + 1]; r.s[2] = s[fan + 2];
+    return triangle_setup(r.s[0], r.s[1], r.s[2], W, H, r.ts);
 }
 
 }  // namespace topo
