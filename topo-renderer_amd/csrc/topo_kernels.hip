@@ -266,11 +266,49 @@ __device__ __forceinline__ void enqueue_rare(const FrameParams& P, uint32_t view
     else atomicOr(&P.counters[2], kStatusRareOverflow);
 }
 
+// Fragment staging: lanes of k_raster do not touch the visibility buffer while they walk their triangles (a
+// dependent global load per covered pixel would stall the whole wave each iteration); they append
+// (pixel, key) pairs to an LDS list which the workgroup then drains densely, one fragment per lane, so the
+// depth pre-test loads of 256 fragments are in flight together.
+#ifndef TOPO_FRAG_CAP
+#define TOPO_FRAG_CAP 256
+#endif
+constexpr uint32_t kFragCap = TOPO_FRAG_CAP;
+struct FragList {
+    uint32_t count;
+    uint32_t pix[kFragCap];
+    uint64_t key[kFragCap];
+};
+
+#ifndef TOPO_INLANE_ROWS
+#define TOPO_INLANE_ROWS 4
+#endif
+#ifndef TOPO_INLANE_COLS
+#define TOPO_INLANE_COLS 16
+#endif
+constexpr int32_t kInlaneRows = TOPO_INLANE_ROWS, kInlaneCols = TOPO_INLANE_COLS;
+
+__device__ __forceinline__ void frag_push(FragList& fl, uint64_t* __restrict__ vis, uint32_t pix, uint64_t key) {
+#ifdef TOPO_NO_FRAGLIST
+    vis_min(vis + pix, key);
+    return;
+#endif
+    const uint32_t slot = atomicAdd(&fl.count, 1u);
+    if (slot < kFragCap) {
+        fl.pix[slot] = pix;
+        fl.key[slot] = key;
+    } else {
+        vis_min(vis + pix, key);   // list full: fall back to the direct path
+    }
+}
+
 // The common case: a triangle whose three snapped vertices span < 64 px.  Everything fits int32 (|delta| < 2^14
 // so every product is < 2^28); the integers are the same ones triangle_setup/triangle_pixel compute in int64, so
-// coverage, barycentrics and depth are bit-identical.  Edge functions are stepped incrementally.
-__device__ __forceinline__ void raster_small(const FrameParams& P, uint64_t* __restrict__ vis, const SVert& s0, const SVert& s1,
-                                             const SVert& s2, uint32_t view, uint32_t id) {
+// coverage, barycentrics and depth are bit-identical.  Boxes of up to 8 rows are walked in-lane, row by row:
+// a float estimate of each edge's crossing narrows the row to its covered span (padded by a pixel either side),
+// the exact integer test then decides every pixel, so the estimate can only cost time, never change coverage.
+__device__ __forceinline__ void raster_small(const FrameParams& P, FragList& fl, uint64_t* __restrict__ vis, const SVert& s0,
+                                             const SVert& s1, const SVert& s2, uint32_t view, uint32_t id) {
     const int32_t X0 = s0.X, Y0 = s0.Y, X1 = s1.X, Y1 = s1.Y, X2 = s2.X, Y2 = s2.Y;
     const int32_t mnx = min(X0, min(X1, X2)), mxx = max(X0, max(X1, X2));
     const int32_t mny = min(Y0, min(Y1, Y2)), mxy = max(Y0, max(Y1, Y2));
@@ -286,7 +324,7 @@ __device__ __forceinline__ void raster_small(const FrameParams& P, uint64_t* __r
     px1 = min(px1, P.W - 1);
     py1 = min(py1, P.H - 1);
     if (px0 > px1 || py0 > py1) return;
-    if (px1 - px0 >= 4 || py1 - py0 >= 4) {
+    if (py1 - py0 >= kInlaneRows || px1 - px0 >= kInlaneCols) {
         if (!enqueue_big(P, view, id, s0, s1, s2, px0, px1, py0, py1)) enqueue_rare(P, view, id >> 1);
         return;
     }
@@ -296,25 +334,39 @@ __device__ __forceinline__ void raster_small(const FrameParams& P, uint64_t* __r
     const int32_t b1 = ((dy1 > 0) || (dy1 == 0 && dx1 < 0)) ? 0 : -1;
     const int32_t b2 = ((dy2 > 0) || (dy2 == 0 && dx2 < 0)) ? 0 : -1;
     const int32_t cx = px0 * 256 + 128, cy = py0 * 256 + 128;
-    int32_t r0 = dy0 * (cx - X1) - dx0 * (cy - Y1);
-    int32_t r1 = dy1 * (cx - X2) - dx1 * (cy - Y2);
-    int32_t r2 = dy2 * (cx - X0) - dx2 * (cy - Y0);
+    int32_t r0 = dy0 * (cx - X1) - dx0 * (cy - Y1) + b0;      // biased: covered <=> all three >= 0
+    int32_t r1 = dy1 * (cx - X2) - dx1 * (cy - Y2) + b1;
+    int32_t r2 = dy2 * (cx - X0) - dx2 * (cy - Y0) + b2;
+    const int32_t m0 = dy0 * 256, m1 = dy1 * 256, m2 = dy2 * 256;
+    const float i0 = m0 ? 1.0f / (float)m0 : 0.0f, i1 = m1 ? 1.0f / (float)m1 : 0.0f, i2 = m2 ? 1.0f / (float)m2 : 0.0f;
     const float fA = (float)(-area2);
     const float z0 = s0.z, dz1 = s1.z - s0.z, dz2 = s2.z - s0.z;
+    const int32_t nx = px1 - px0;
     for (int32_t py = py0; py <= py1; ++py) {
-        int32_t F0 = r0, F1 = r1, F2 = r2;
-        for (int32_t px = px0; px <= px1; ++px) {
-            if (((F0 + b0) | (F1 + b1) | (F2 + b2)) >= 0) {
-                const float w1 = (float)F1 / fA, w2 = (float)F2 / fA;
-                float z = z0 + (w1 * dz1 + w2 * dz2);
-                if (z < 1.0f) {
-                    if (z < 0.0f) z = 0.0f;
-                    vis_min(vis + (size_t)py * P.W + px, vis_key(z, id));
+        // conservative span [lo, hi] (relative to px0) from each edge's crossing -r/m
+        int32_t lo = 0, hi = nx;
+        bool dead = false;
+        {
+            const float q0 = -(float)r0 * i0, q1 = -(float)r1 * i1, q2 = -(float)r2 * i2;
+            if (m0 > 0) lo = max(lo, (int32_t)q0 - 1); else if (m0 < 0) hi = min(hi, (int32_t)q0 + 1); else dead |= r0 < 0;
+            if (m1 > 0) lo = max(lo, (int32_t)q1 - 1); else if (m1 < 0) hi = min(hi, (int32_t)q1 + 1); else dead |= r1 < 0;
+            if (m2 > 0) lo = max(lo, (int32_t)q2 - 1); else if (m2 < 0) hi = min(hi, (int32_t)q2 + 1); else dead |= r2 < 0;
+        }
+        if (!dead) {
+            int32_t F0 = r0 + m0 * lo, F1 = r1 + m1 * lo, F2 = r2 + m2 * lo;
+            for (int32_t k = lo; k <= hi; ++k) {
+                if ((F0 | F1 | F2) >= 0) {
+                    const float w1 = (float)(F1 - b1) / fA, w2 = (float)(F2 - b2) / fA;
+                    float z = z0 + (w1 * dz1 + w2 * dz2);
+                    if (z < 1.0f) {
+                        if (z < 0.0f) z = 0.0f;
+                        frag_push(fl, vis, (uint32_t)(py * P.W + px0 + k), vis_key(z, id));
+                    }
                 }
+                F0 += m0;
+                F1 += m1;
+                F2 += m2;
             }
-            F0 += dy0 * 256;
-            F1 += dy1 * 256;
-            F2 += dy2 * 256;
         }
         r0 -= dx0 * 256;
         r1 -= dx1 * 256;
@@ -322,78 +374,95 @@ __device__ __forceinline__ void raster_small(const FrameParams& P, uint64_t* __r
     }
 }
 
-// One workgroup per surviving (view, tile, block): stage the block's post-transform vertices in LDS
-// (each vertex transformed once from coalesced 244-B row reads of the DEM; sin/cos once per row and column),
-// then one lane per grid cell sets up and rasterises its two triangles.
+__device__ __forceinline__ SVert shfl_down1(const SVert& v) {
+    SVert o;
+    o.X = __shfl_down(v.X, 1);
+    o.Y = __shfl_down(v.Y, 1);
+    o.z = __shfl_down(v.z, 1);
+    o.flag = __shfl_down(v.flag, 1);
+    return o;
+}
+
+// One WAVE per surviving (view, tile, block) -- no workgroup barriers, no LDS vertex staging.  Lane i owns
+// vertex column x0+i of the block (61 of 64 lanes); the wave walks the block's 16 vertex rows top to bottom,
+// each lane transforming one vertex per row (coalesced 244-B row reads of the DEM, the next row's heights
+// prefetched while the current row is processed; sin/cos of the longitude once per lane, of the latitudes once
+// per row on lanes 0..15 and broadcast).  The previous row stays in registers; lane i then owns grid cell
+// (x0+i, row-1): its four corners are its own two vertices and lane i+1's two, fetched with wave shuffles.
+// Fragments go to a per-wave LDS list that the wave drains densely (one fragment per lane) whenever a row left
+// more than a wave's worth in it.
 __global__ __launch_bounds__(256) void k_raster(FrameParams P) {
-    __shared__ SVert sv[kVY][kVX];
-    __shared__ float2 s_lat[kVY], s_lon[kVX];      // (sin, cos)
+    __shared__ FragList s_fl[4];
     uint32_t count = P.counters[0];
     if (count > P.work_cap) count = P.work_cap;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (uint32_t item = blockIdx.x; item < count; item += gridDim.x) {
+    FragList& fl = s_fl[wave];
+    const uint32_t wave_global = blockIdx.x * 4 + wave, wave_count = gridDim.x * 4;
+    for (uint32_t item = wave_global; item < count; item += wave_count) {
         const WorkItem wi = P.work[item];
         const uint32_t view_idx = wi.view_rank >> 16, rank = wi.view_rank & 0xFFFFu;
         const TileDev& t = P.tiles[rank];
         const ViewDev& view = P.views[view_idx];
         const uint32_t bx = wi.block % P.bx_count, by = wi.block / P.bx_count;
         const uint32_t x0 = bx * kBCX, y0 = by * kBCY;
-        // ---- phase 0: sin/cos of the block's rows and columns
-        if (threadIdx.x < kVX) {
-            float sn, cs;
-            sincos_f(vertex_lon(t, x0 + threadIdx.x), sn, cs);
-            s_lon[threadIdx.x] = make_float2(sn, cs);
-        } else if (threadIdx.x >= 64 && threadIdx.x < 64 + kVY) {
-            float sn, cs;
-            sincos_f(vertex_lat(t, y0 + threadIdx.x - 64), sn, cs);
-            s_lat[threadIdx.x - 64] = make_float2(sn, cs);
-        }
-        __syncthreads();
-        // ---- phase 1: vertices
-        if (lane < kVX) {
-            const uint32_t vx = x0 + lane;
-            const float2 lo = s_lon[lane];
-            for (uint32_t r = wave; r < kVY; r += 4) {
-                const uint32_t vy = y0 + r;
-                SVert s;
-                s.X = 0; s.Y = 0; s.z = 0.0f; s.flag = kVtxNear;
-                if (vx < P.tile_w && vy < P.tile_h) {
-                    const float2 la = s_lat[r];
-                    const f3 p = world_from_sincos(t.heights[(size_t)vy * P.tile_w + vx], la.x, la.y, lo.x, lo.y);
-                    float clip[4];
-                    mat4_point(view.proj, p.x, p.y, p.z, clip);
-                    clip_to_screen(clip, (float)P.W, (float)P.H, s);
-                }
-                sv[r][lane] = s;
-            }
-        }
-        __syncthreads();
-        // ---- phase 2: cells
+        const uint32_t nrows = min(kVY, P.tile_h - y0);          // vertex rows in this block
+        const uint32_t ncx = min(kBCX, P.tile_w - 1 - x0);       // cells per row
+        const uint32_t vx = x0 + lane;
+        const bool vcol = lane < kVX && vx < P.tile_w;
         uint64_t* vis = P.vis + (size_t)view_idx * P.W * P.H;
-        const uint32_t ncx = min(kBCX, P.tile_w - 1 - x0), ncy = min(kBCY, P.tile_h - 1 - y0);
-        for (uint32_t c = threadIdx.x; c < ncx * ncy; c += 256) {
-            const uint32_t cy = c / ncx, cx = c - cy * ncx;
-            const uint32_t i = x0 + cx, j = y0 + cy;
-            const SVert a = sv[cy][cx], b = sv[cy + 1][cx], cc = sv[cy][cx + 1], d = sv[cy + 1][cx + 1];
-            const bool even = ((i + j) & 1u) == 0;
-            const uint32_t tri0 = (i * (P.tile_h - 1) + j) * 2;
-#pragma unroll
-            for (uint32_t k = 0; k < 2; ++k) {
-                const SVert& s0 = k == 0 ? a : d;
-                const SVert& s1 = k == 0 ? b : cc;
-                const SVert& s2 = k == 0 ? (even ? d : cc) : (even ? a : b);
-                const uint32_t tri = tri0 + k;
-                const uint32_t draw = rank * P.tris_per_tile + tri;
-                const int fl = s0.flag | s1.flag | s2.flag;
-                if (fl == kVtxOk) {
-                    raster_small(P, vis, s0, s1, s2, view_idx, draw << 1);
-                } else if (fl & kVtxNear) {
-                    const int nnear = (s0.flag == kVtxNear) + (s1.flag == kVtxNear) + (s2.flag == kVtxNear);
-                    if (nnear != 3) enqueue_rare(P, view_idx, draw);
-                }   // else: guard band -> primitive discarded
+        if (lane == 0) fl.count = 0;
+        float slo, clo, lat_s = 0.0f, lat_c = 0.0f;
+        sincos_f(vertex_lon(t, vcol ? vx : x0), slo, clo);
+        if (lane < nrows) sincos_f(vertex_lat(t, y0 + lane), lat_s, lat_c);
+        const float* hcol = t.heights + (size_t)y0 * P.tile_w + (vcol ? vx : x0);
+        float h_next = *hcol;
+        SVert prev;
+        prev.X = 0; prev.Y = 0; prev.z = 0.0f; prev.flag = kVtxNear;
+        for (uint32_t r = 0; r < nrows; ++r) {
+            const float h = h_next;
+            if (r + 1 < nrows) h_next = hcol[(size_t)(r + 1) * P.tile_w];
+            const float sla = __shfl(lat_s, (int)r), cla = __shfl(lat_c, (int)r);
+            SVert cur;
+            cur.X = 0; cur.Y = 0; cur.z = 0.0f; cur.flag = kVtxNear;
+            if (vcol) {
+                const f3 p = world_from_sincos(h, sla, cla, slo, clo);
+                float clip[4];
+                mat4_point(view.proj, p.x, p.y, p.z, clip);
+                clip_to_screen(clip, (float)P.W, (float)P.H, cur);
             }
+            if (r > 0) {
+                // cell (i, j) = (x0 + lane, y0 + r - 1): a = (i,j) b = (i,j+1) c = (i+1,j) d = (i+1,j+1)
+                const SVert cc = shfl_down1(prev), d = shfl_down1(cur);
+                if (lane < ncx) {
+                    const SVert &a = prev, &b = cur;
+                    const uint32_t i = x0 + lane, j = y0 + r - 1;
+                    const bool even = ((i + j) & 1u) == 0;
+                    const uint32_t tri0 = (i * (P.tile_h - 1) + j) * 2;
+#pragma unroll
+                    for (uint32_t k = 0; k < 2; ++k) {
+                        const SVert& s0 = k == 0 ? a : d;
+                        const SVert& s1 = k == 0 ? b : cc;
+                        const SVert& s2 = k == 0 ? (even ? d : cc) : (even ? a : b);
+                        const uint32_t tri = tri0 + k;
+                        const uint32_t draw = rank * P.tris_per_tile + tri;
+                        const int fg = s0.flag | s1.flag | s2.flag;
+                        if (fg == kVtxOk) {
+                            raster_small(P, fl, vis, s0, s1, s2, view_idx, draw << 1);
+                        } else if (fg & kVtxNear) {
+                            const int nnear = (s0.flag == kVtxNear) + (s1.flag == kVtxNear) + (s2.flag == kVtxNear);
+                            if (nnear != 3) enqueue_rare(P, view_idx, draw);
+                        }   // else: guard band -> primitive discarded
+                    }
+                }
+                // drain once at least a wave's worth of fragments is waiting (or at the block's end)
+                const uint32_t nfrag = min(fl.count, kFragCap);
+                if (nfrag >= 64 || r + 1 == nrows) {
+                    for (uint32_t f = lane; f < nfrag; f += 64) vis_min(vis + fl.pix[f], fl.key[f]);
+                    if (lane == 0) fl.count = 0;
+                }
+            }
+            prev = cur;
         }
-        __syncthreads();
     }
 }
 
@@ -418,33 +487,99 @@ __global__ __launch_bounds__(256) void k_raster_rare(FrameParams P) {
     }
 }
 
+// Depth pre-test + atomic for up to four candidate fragments of one lane with all four loads in flight
+// together (the sweep below is latency-bound otherwise).  key == kVisClear marks "no fragment" (no real key
+// equals it: ids are < 0xFFFFFFFF and depths < 1.0).
+__device__ __forceinline__ void vis_min4(uint64_t* __restrict__ vis, const uint32_t pix[4], const uint64_t key[4]) {
+    uint64_t cur[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        cur[k] = key[k] != kVisClear ? __hip_atomic_load(vis + pix[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (key[k] < cur[k]) atomicMin(reinterpret_cast<unsigned long long*>(vis + pix[k]), (unsigned long long)key[k]);
+}
+
 // One wave per BigItem: the item carries the snapped vertices, so every lane re-runs the exact integer setup
-// (wave-uniform) and the wave sweeps the 8x8 px sub-chunks of the item's 64x64 region that intersect the
-// triangle's pixel box, one pixel per lane.
+// (wave-uniform) and the wave sweeps the item's 64x64 region in strips of four 8x8 px sub-chunks, one pixel per
+// lane and sub-chunk.  Triangles spanning < 64 px (all that k_raster enqueues) take the int32 form of the same
+// integers; the giants that come through k_raster_rare take the int64 form.
 __global__ __launch_bounds__(256) void k_raster_big(FrameParams P) {
     uint32_t count = P.counters[1];
     if (count > P.big_cap) count = P.big_cap;
     const uint32_t lane = threadIdx.x & 63;
+    const int32_t lx = (int32_t)(lane & 7), ly = (int32_t)(lane >> 3);
     const uint32_t wave_global = blockIdx.x * 4 + (threadIdx.x >> 6), wave_count = gridDim.x * 4;
     for (uint32_t item = wave_global; item < count; item += wave_count) {
         const BigItem bi = P.big[item];
         if (bi.id == kNoTri) continue;
+        uint64_t* vis = P.vis + (size_t)bi.view * P.W * P.H;
+        const int32_t rx = (int32_t)(bi.region & 0xFFFFu), ry = (int32_t)(bi.region >> 16);
+        const int32_t X0 = bi.X[0], Y0 = bi.Y[0], X1 = bi.X[1], Y1 = bi.Y[1], X2 = bi.X[2], Y2 = bi.Y[2];
+        const int32_t mnx = min(X0, min(X1, X2)), mxx = max(X0, max(X1, X2));
+        const int32_t mny = min(Y0, min(Y1, Y2)), mxy = max(Y0, max(Y1, Y2));
+        if ((mxx - mnx) < (1 << 14) && (mxy - mny) < (1 << 14)) {
+            const int32_t area2 = (X1 - X0) * (Y2 - Y0) - (Y1 - Y0) * (X2 - X0);
+            if (area2 >= 0) continue;
+            int32_t px0 = max((mnx + 127) >> 8, 0), px1 = min((mxx - 128) >> 8, P.W - 1);
+            int32_t py0 = max((mny + 127) >> 8, 0), py1 = min((mxy - 128) >> 8, P.H - 1);
+            px0 = max(px0, rx * 64); px1 = min(px1, rx * 64 + 63);
+            py0 = max(py0, ry * 64); py1 = min(py1, ry * 64 + 63);
+            const int32_t dx0 = X2 - X1, dy0 = Y2 - Y1, dx1 = X0 - X2, dy1 = Y0 - Y2, dx2 = X1 - X0, dy2 = Y1 - Y0;
+            const int32_t b0 = ((dy0 > 0) || (dy0 == 0 && dx0 < 0)) ? 0 : -1;
+            const int32_t b1 = ((dy1 > 0) || (dy1 == 0 && dx1 < 0)) ? 0 : -1;
+            const int32_t b2 = ((dy2 > 0) || (dy2 == 0 && dx2 < 0)) ? 0 : -1;
+            const float fA = (float)(-area2);
+            const float z0 = bi.z[0], dz1 = bi.z[1] - bi.z[0], dz2 = bi.z[2] - bi.z[0];
+            for (int32_t sy = py0 & ~7; sy <= py1; sy += 8)
+                for (int32_t sx = px0 & ~7; sx <= px1; sx += 32) {
+                    uint32_t pix[4];
+                    uint64_t key[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int32_t px = sx + 8 * k + lx, py = sy + ly;
+                        key[k] = kVisClear;
+                        pix[k] = 0;
+                        if (px < px0 || px > px1 || py < py0 || py > py1) continue;
+                        const int32_t cx = px * 256 + 128, cy = py * 256 + 128;
+                        const int32_t F0 = dy0 * (cx - X1) - dx0 * (cy - Y1);
+                        const int32_t F1 = dy1 * (cx - X2) - dx1 * (cy - Y2);
+                        const int32_t F2 = dy2 * (cx - X0) - dx2 * (cy - Y0);
+                        if (((F0 + b0) | (F1 + b1) | (F2 + b2)) < 0) continue;
+                        const float w1 = (float)F1 / fA, w2 = (float)F2 / fA;
+                        float z = z0 + (w1 * dz1 + w2 * dz2);
+                        if (!(z < 1.0f)) continue;
+                        if (z < 0.0f) z = 0.0f;
+                        pix[k] = (uint32_t)(py * P.W + px);
+                        key[k] = vis_key(z, bi.id);
+                    }
+                    vis_min4(vis, pix, key);
+                }
+            continue;
+        }
         SVert s[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) { s[k].X = bi.X[k]; s[k].Y = bi.Y[k]; s[k].z = bi.z[k]; s[k].flag = kVtxOk; }
         TriSetup ts;
         if (!triangle_setup(s[0], s[1], s[2], P.W, P.H, ts)) continue;
-        uint64_t* vis = P.vis + (size_t)bi.view * P.W * P.H;
-        const int32_t rx = (int32_t)(bi.region & 0xFFFFu), ry = (int32_t)(bi.region >> 16);
         const int32_t bx0 = max(ts.px0, rx * 64), bx1 = min(ts.px1, rx * 64 + 63);
         const int32_t by0 = max(ts.py0, ry * 64), by1 = min(ts.py1, ry * 64 + 63);
-        const int32_t lx = (int32_t)(lane & 7), ly = (int32_t)(lane >> 3);
         for (int32_t sy = by0 & ~7; sy <= by1; sy += 8)
-            for (int32_t sx = bx0 & ~7; sx <= bx1; sx += 8) {
-                const int32_t px = sx + lx, py = sy + ly;
-                if (px < bx0 || px > bx1 || py < by0 || py > by1) continue;
-                float z, b[3];
-                if (triangle_pixel(ts, px, py, z, b)) vis_min(vis + (size_t)py * P.W + px, vis_key(z, bi.id));
+            for (int32_t sx = bx0 & ~7; sx <= bx1; sx += 32) {
+                uint32_t pix[4];
+                uint64_t key[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int32_t px = sx + 8 * k + lx, py = sy + ly;
+                    key[k] = kVisClear;
+                    pix[k] = 0;
+                    if (px < bx0 || px > bx1 || py < by0 || py > by1) continue;
+                    float z, b[3];
+                    if (!triangle_pixel(ts, px, py, z, b)) continue;
+                    pix[k] = (uint32_t)(py * P.W + px);
+                    key[k] = vis_key(z, bi.id);
+                }
+                vis_min4(vis, pix, key);
             }
     }
 }
@@ -567,7 +702,7 @@ void launch_cull(const FrameParams& p, hipStream_t s) {
 
 void launch_raster(const FrameParams& p, hipStream_t s) {
     if (p.n_tiles == 0) return;
-    hipLaunchKernelGGL(k_raster, dim3(256 * 8), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(k_raster, dim3(256 * 8), dim3(256), 0, s, p);   // 8192 waves, each strides over the work list
 }
 
 void launch_raster_rare(const FrameParams& p, hipStream_t s) {
