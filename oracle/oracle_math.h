@@ -3,8 +3,8 @@
  *
  * Scalar f32 arithmetic the CPU oracle uses to restate the reference's WGSL.  WGSL leaves the
  * precision of sin/cos/normalize and FMA contraction to the implementation, so the build freezes
- * one definition (DESIGN.md "Arithmetic spec"): IEEE-754 binary32 add/sub/mul/div/sqrt, no
- * contraction (compile with -ffp-contract=off), left-to-right evaluation as written in the WGSL,
+ * one definition (DESIGN.md "Arithmetic spec"): IEEE-754 binary32 add/sub/mul/div/sqrt, fma only
+ * where fmaf() is written (compile with -ffp-contract=off), evaluation order as written here,
  * and the sin/cos below.  This header is written independently of the product's device header
  * (topo-renderer_amd/csrc/topo_math.h); tests compare the two bit-for-bit.
  */
@@ -26,10 +26,10 @@ static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 static inline float radians(float deg) { return deg * 0.017453292519943295f; }
 
 /*
- * sin/cos spec: k = rint(x * 2/pi); r = ((x - k*P1) - k*P2) - k*P3 (Cody-Waite, P1 has 8
- * significant bits so k*P1 is exact for |k| < 2^16); z = r*r;
- *   sin(r) = r + r*z*(S1 + z*(S2 + z*S3)),  cos(r) = (1 - 0.5*z) + z*z*(C1 + z*(C2 + z*C3))
+ * sin/cos spec: k = rint(x * 2/pi); r = fma(-k,P3, fma(-k,P2, fma(-k,P1, x))) (Cody-Waite); z = r*r;
+ *   sin(r) = fma(r*z, fma(fma(S3,z,S2), z, S1), r),  cos(r) = fma(z*z, fma(fma(C3,z,C2), z, C1), fma(-0.5,z,1))
  * (Cephes single-precision minimax coefficients, |r| <= pi/4, error < 1 ulp), then quadrant fix-up.
+ * fmaf() is the correctly rounded fused multiply-add on every platform (hardware or libm).
  */
 static inline void sincos_spec(float x, float* s_out, float* c_out) {
     const float TWO_OVER_PI = 0.63661977236758134f;
@@ -37,18 +37,16 @@ static inline void sincos_spec(float x, float* s_out, float* c_out) {
     const float P2 = 4.837512969970703125e-4f;
     const float P3 = 7.54978995489188e-8f;
     float k = rintf(x * TWO_OVER_PI);
-    float r = x - k * P1;
-    r = r - k * P2;
-    r = r - k * P3;
+    float r = fmaf(-k, P1, x);
+    r = fmaf(-k, P2, r);
+    r = fmaf(-k, P3, r);
     float z = r * r;
-    float ps = -1.9515295891e-4f;
-    ps = ps * z + 8.3321608736e-3f;
-    ps = ps * z + -1.6666654611e-1f;
-    float s = r + r * z * ps;
-    float pc = 2.443315711809948e-5f;
-    pc = pc * z + -1.388731625493765e-3f;
-    pc = pc * z + 4.166664568298827e-2f;
-    float c = (1.0f - 0.5f * z) + z * z * pc;
+    float ps = fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
+    ps = fmaf(ps, z, -1.6666654611e-1f);
+    float s = fmaf(r * z, ps, r);
+    float pc = fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+    pc = fmaf(pc, z, 4.166664568298827e-2f);
+    float c = fmaf(z * z, pc, fmaf(-0.5f, z, 1.0f));
     int q = ((int)k) & 3;
     float so, co;
     switch (q) {
@@ -93,7 +91,16 @@ static inline uint8_t unorm8(float v) { return (uint8_t)floorf(clamp01(v) * 255.
 /* unorm8 -> float (textureLoad from rgba8unorm) */
 static inline float from_unorm8(uint8_t c) { return (float)c / 255.0f; }
 
-/* mat4 (column-major, 16 floats) * vec4: ((c0*x + c1*y) + c2*z) + c3*w, per component */
+/* GPU shader mat4 (column-major) * vec4(p, 1): per component t = c0*x; t = fma(c1,y,t); t = fma(c2,z,t); t + c3 */
+static inline void mat4_mul_point(const float* m, float x, float y, float z, float* out) {
+    for (int r = 0; r < 4; ++r) {
+        float acc = m[0 + r] * x;
+        acc = fmaf(m[4 + r], y, acc);
+        acc = fmaf(m[8 + r], z, acc);
+        out[r] = acc + m[12 + r];
+    }
+}
+/* host (glam) mat4 * vec4: ((c0*x + c1*y) + c2*z) + c3*w, per component, no fma (default x86-64 build) */
 static inline void mat4_mul_vec4(const float* m, float x, float y, float z, float w, float* out) {
     for (int r = 0; r < 4; ++r) {
         float acc = m[0 + r] * x;
@@ -105,10 +112,10 @@ static inline void mat4_mul_vec4(const float* m, float x, float y, float z, floa
 }
 /* upper-left 3x3 of a column-major mat4 times (x,y,z,0); the w=0 column contributes nothing */
 static inline v3 mat4_mul_dir(const float* m, v3 n) {
-    v3 o;
-    o.x = (m[0] * n.x + m[4] * n.y) + m[8] * n.z;
-    o.y = (m[1] * n.x + m[5] * n.y) + m[9] * n.z;
-    o.z = (m[2] * n.x + m[6] * n.y) + m[10] * n.z;
+    v3 o;   /* same fma chain as mat4_mul_point, w = 0 */
+    o.x = fmaf(m[8], n.z, fmaf(m[4], n.y, m[0] * n.x));
+    o.y = fmaf(m[9], n.z, fmaf(m[5], n.y, m[1] * n.x));
+    o.z = fmaf(m[10], n.z, fmaf(m[6], n.y, m[2] * n.x));
     return o;
 }
 

@@ -371,7 +371,7 @@ VSOut vs_main(const Tile& t, uint32_t px, uint32_t py, const Uniforms& u) {
     v3 normal = {2.0f * from_unorm8(n8[0]) - 1.0f, 2.0f * from_unorm8(n8[1]) - 1.0f,
                  2.0f * from_unorm8(n8[2]) - 1.0f};
     o.wnrm = mat4_mul_dir(t.tu.normal_to_world_rot, normal);
-    mat4_mul_vec4(u.camera_proj, o.wpos.x, o.wpos.y, o.wpos.z, 1.0f, o.clip);
+    mat4_mul_point(u.camera_proj, o.wpos.x, o.wpos.y, o.wpos.z, o.clip);
     return o;
 }
 
@@ -427,13 +427,15 @@ struct ScreenVert {
     float z, w;   /* z_ndc, w_clip */
 };
 
-/* Raster spec: viewport transform as WebGPU framebufferCoords, snap to 1/256 pixel
+/* Raster spec: perspective divide by reciprocal, viewport transform as WebGPU framebufferCoords, snap to 1/256 pixel
  * (round-half-even), guard band |coord| <= 2^20 pixels else the triangle is discarded. */
 bool to_screen(const VSOut& v, uint32_t W, uint32_t H, ScreenVert* s) {
     float w = v.clip[3];
-    float nx = v.clip[0] / w, ny = v.clip[1] / w, nz = v.clip[2] / w;
-    float xf = (0.5f * (nx + 1.0f)) * (float)W;
-    float yf = (0.5f * (1.0f - ny)) * (float)H;
+    float rw = 1.0f / w;                                   /* perspective divide: reciprocal, then multiplies */
+    float nx = v.clip[0] * rw, ny = v.clip[1] * rw, nz = v.clip[2] * rw;
+    float half_w = 0.5f * (float)W, half_h = 0.5f * (float)H;
+    float xf = fmaf(nx, half_w, half_w);                   /* 0.5 * (ndc.x + 1) * W */
+    float yf = fmaf(-ny, half_h, half_h);                  /* 0.5 * (1 - ndc.y) * H */
     if (!(fabsf(xf) <= 1048576.0f) || !(fabsf(yf) <= 1048576.0f)) return false;
     s->X = (int64_t)rintf(xf * 256.0f);
     s->Y = (int64_t)rintf(yf * 256.0f);
@@ -474,29 +476,29 @@ void raster_triangle(Frame& f, const Uniforms& u, const VSOut& v0, const VSOut& 
     };
     const Edge e12 = mk(s1, s2), e20 = mk(s2, s0), e01 = mk(s0, s1);
     auto ev = [](const Edge& e, int64_t px, int64_t py) { return e.dy * (px - e.ax) - e.dx * (py - e.ay); };
-    const float fA = (float)A;
+    const float rA = 1.0f / (float)A;
     const float dz1 = s1.z - s0.z, dz2 = s2.z - s0.z;
     for (int64_t py = y0; py <= y1; ++py)
         for (int64_t px = x0; px <= x1; ++px) {
             const int64_t cx = px * 256 + 128, cy = py * 256 + 128;
             const int64_t F0 = ev(e12, cx, cy), F1 = ev(e20, cx, cy), F2 = ev(e01, cx, cy);
             if (F0 + e12.bias < 0 || F1 + e20.bias < 0 || F2 + e01.bias < 0) continue;
-            const float b0 = (float)F0 / fA, b1 = (float)F1 / fA, b2 = (float)F2 / fA;
-            float z = s0.z + (b1 * dz1 + b2 * dz2);
+            const float b0 = (float)F0 * rA, b1 = (float)F1 * rA, b2 = (float)F2 * rA;
+            float z = fmaf(b1, dz1, fmaf(b2, dz2, s0.z));
             if (!(z < 1.0f)) continue; /* far plane (and NaN) */
             if (z < 0.0f) z = 0.0f;
             const size_t p = (size_t)py * f.W + (size_t)px;
             if (!(z < f.depth[p])) continue; /* CompareFunction::Less */
             /* perspective-correct varyings */
-            const float q0 = b0 / s0.w, q1 = b1 / s1.w, q2 = b2 / s2.w;
-            const float qs = (q0 + q1) + q2;
+            const float q0 = b0 * (1.0f / s0.w), q1 = b1 * (1.0f / s1.w), q2 = b2 * (1.0f / s2.w);
+            const float rq = 1.0f / ((q0 + q1) + q2);
             v3 wpos, wnrm;
-            wpos.x = ((v0.wpos.x * q0 + v1.wpos.x * q1) + v2.wpos.x * q2) / qs;
-            wpos.y = ((v0.wpos.y * q0 + v1.wpos.y * q1) + v2.wpos.y * q2) / qs;
-            wpos.z = ((v0.wpos.z * q0 + v1.wpos.z * q1) + v2.wpos.z * q2) / qs;
-            wnrm.x = ((v0.wnrm.x * q0 + v1.wnrm.x * q1) + v2.wnrm.x * q2) / qs;
-            wnrm.y = ((v0.wnrm.y * q0 + v1.wnrm.y * q1) + v2.wnrm.y * q2) / qs;
-            wnrm.z = ((v0.wnrm.z * q0 + v1.wnrm.z * q1) + v2.wnrm.z * q2) / qs;
+            wpos.x = fmaf(v2.wpos.x, q2, fmaf(v1.wpos.x, q1, v0.wpos.x * q0)) * rq;
+            wpos.y = fmaf(v2.wpos.y, q2, fmaf(v1.wpos.y, q1, v0.wpos.y * q0)) * rq;
+            wpos.z = fmaf(v2.wpos.z, q2, fmaf(v1.wpos.z, q1, v0.wpos.z * q0)) * rq;
+            wnrm.x = fmaf(v2.wnrm.x, q2, fmaf(v1.wnrm.x, q1, v0.wnrm.x * q0)) * rq;
+            wnrm.y = fmaf(v2.wnrm.y, q2, fmaf(v1.wnrm.y, q1, v0.wnrm.y * q0)) * rq;
+            wnrm.z = fmaf(v2.wnrm.z, q2, fmaf(v1.wnrm.z, q1, v0.wnrm.z * q0)) * rq;
             float c[4];
             fs_main(u, (float)px + 0.5f, (float)py + 0.5f, wpos, wnrm, c);
             f.depth[p] = z;

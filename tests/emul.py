@@ -23,7 +23,7 @@ def lib():
         hdrs = [os.path.join(_HERE, "..", "topo-renderer_amd", "csrc", f) for f in ("topo_math.h", "topo_pipeline.h", "srgb_tables.h")]
         os.makedirs(os.path.dirname(_SO), exist_ok=True)
         if not os.path.exists(_SO) or any(os.path.getmtime(f) > os.path.getmtime(_SO) for f in [src] + hdrs):
-            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-shared",
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-mfma", "-shared",
                                    "-o", _SO, src])
         _LIB = C.CDLL(_SO)
         _LIB.emul_render.restype = C.c_int

@@ -293,6 +293,10 @@ __device__ __forceinline__ void frag_push(FragList& fl, uint64_t* __restrict__ v
     vis_min(vis + pix, key);
     return;
 #endif
+#ifdef TOPO_ABL_NOFRAG          // timing ablation only: fragments are computed and dropped
+    asm volatile("" ::"v"(pix), "v"(key));
+    return;
+#endif
     const uint32_t slot = atomicAdd(&fl.count, 1u);
     if (slot < kFragCap) {
         fl.pix[slot] = pix;
@@ -316,7 +320,8 @@ __device__ __forceinline__ void raster_small(const FrameParams& P, FragList& fl,
         enqueue_rare(P, view, id >> 1);
         return;
     }
-    const int32_t area2 = (X1 - X0) * (Y2 - Y0) - (Y1 - Y0) * (X2 - X0);
+    // all deltas are < 2^14 in magnitude: 24-bit multiplies (full rate) give the exact products
+    const int32_t area2 = __mul24(X1 - X0, Y2 - Y0) - __mul24(Y1 - Y0, X2 - X0);
     if (area2 >= 0) return;
     int32_t px0 = (mnx + 127) >> 8, px1 = (mxx - 128) >> 8, py0 = (mny + 127) >> 8, py1 = (mxy - 128) >> 8;
     px0 = max(px0, 0);
@@ -334,12 +339,14 @@ __device__ __forceinline__ void raster_small(const FrameParams& P, FragList& fl,
     const int32_t b1 = ((dy1 > 0) || (dy1 == 0 && dx1 < 0)) ? 0 : -1;
     const int32_t b2 = ((dy2 > 0) || (dy2 == 0 && dx2 < 0)) ? 0 : -1;
     const int32_t cx = px0 * 256 + 128, cy = py0 * 256 + 128;
-    int32_t r0 = dy0 * (cx - X1) - dx0 * (cy - Y1) + b0;      // biased: covered <=> all three >= 0
-    int32_t r1 = dy1 * (cx - X2) - dx1 * (cy - Y2) + b1;
-    int32_t r2 = dy2 * (cx - X0) - dx2 * (cy - Y0) + b2;
+    int32_t r0 = __mul24(dy0, cx - X1) - __mul24(dx0, cy - Y1) + b0;      // biased: covered <=> all three >= 0
+    int32_t r1 = __mul24(dy1, cx - X2) - __mul24(dx1, cy - Y2) + b1;
+    int32_t r2 = __mul24(dy2, cx - X0) - __mul24(dx2, cy - Y0) + b2;
     const int32_t m0 = dy0 * 256, m1 = dy1 * 256, m2 = dy2 * 256;
-    const float i0 = m0 ? 1.0f / (float)m0 : 0.0f, i1 = m1 ? 1.0f / (float)m1 : 0.0f, i2 = m2 ? 1.0f / (float)m2 : 0.0f;
-    const float fA = (float)(-area2);
+    // hardware reciprocal (v_rcp_f32) is plenty for the span ESTIMATE
+    const float i0 = m0 ? __builtin_amdgcn_rcpf((float)m0) : 0.0f, i1 = m1 ? __builtin_amdgcn_rcpf((float)m1) : 0.0f,
+                i2 = m2 ? __builtin_amdgcn_rcpf((float)m2) : 0.0f;
+    const float iA = 1.0f / (float)(-area2);
     const float z0 = s0.z, dz1 = s1.z - s0.z, dz2 = s2.z - s0.z;
     const int32_t nx = px1 - px0;
     for (int32_t py = py0; py <= py1; ++py) {
@@ -356,8 +363,8 @@ __device__ __forceinline__ void raster_small(const FrameParams& P, FragList& fl,
             int32_t F0 = r0 + m0 * lo, F1 = r1 + m1 * lo, F2 = r2 + m2 * lo;
             for (int32_t k = lo; k <= hi; ++k) {
                 if ((F0 | F1 | F2) >= 0) {
-                    const float w1 = (float)(F1 - b1) / fA, w2 = (float)(F2 - b2) / fA;
-                    float z = z0 + (w1 * dz1 + w2 * dz2);
+                    const float w1 = (float)(F1 - b1) * iA, w2 = (float)(F2 - b2) * iA;
+                    float z = fmaf(w1, dz1, fmaf(w2, dz2, z0));
                     if (z < 1.0f) {
                         if (z < 0.0f) z = 0.0f;
                         frag_push(fl, vis, (uint32_t)(py * P.W + px0 + k), vis_key(z, id));
@@ -430,7 +437,12 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams P) {
                 mat4_point(view.proj, p.x, p.y, p.z, clip);
                 clip_to_screen(clip, (float)P.W, (float)P.H, cur);
             }
+#ifdef TOPO_ABL_NOTRI            // timing ablation only: vertex transform alone
+            asm volatile("" ::"v"(cur.X), "v"(cur.Y), "v"(cur.z), "v"(cur.flag));
+            if (false) {
+#else
             if (r > 0) {
+#endif
                 // cell (i, j) = (x0 + lane, y0 + r - 1): a = (i,j) b = (i,j+1) c = (i+1,j) d = (i+1,j+1)
                 const SVert cc = shfl_down1(prev), d = shfl_down1(cur);
                 if (lane < ncx) {
@@ -519,7 +531,7 @@ __global__ __launch_bounds__(256) void k_raster_big(FrameParams P) {
         const int32_t mnx = min(X0, min(X1, X2)), mxx = max(X0, max(X1, X2));
         const int32_t mny = min(Y0, min(Y1, Y2)), mxy = max(Y0, max(Y1, Y2));
         if ((mxx - mnx) < (1 << 14) && (mxy - mny) < (1 << 14)) {
-            const int32_t area2 = (X1 - X0) * (Y2 - Y0) - (Y1 - Y0) * (X2 - X0);
+            const int32_t area2 = __mul24(X1 - X0, Y2 - Y0) - __mul24(Y1 - Y0, X2 - X0);
             if (area2 >= 0) continue;
             int32_t px0 = max((mnx + 127) >> 8, 0), px1 = min((mxx - 128) >> 8, P.W - 1);
             int32_t py0 = max((mny + 127) >> 8, 0), py1 = min((mxy - 128) >> 8, P.H - 1);
@@ -529,7 +541,7 @@ __global__ __launch_bounds__(256) void k_raster_big(FrameParams P) {
             const int32_t b0 = ((dy0 > 0) || (dy0 == 0 && dx0 < 0)) ? 0 : -1;
             const int32_t b1 = ((dy1 > 0) || (dy1 == 0 && dx1 < 0)) ? 0 : -1;
             const int32_t b2 = ((dy2 > 0) || (dy2 == 0 && dx2 < 0)) ? 0 : -1;
-            const float fA = (float)(-area2);
+            const float iA = 1.0f / (float)(-area2);
             const float z0 = bi.z[0], dz1 = bi.z[1] - bi.z[0], dz2 = bi.z[2] - bi.z[0];
             for (int32_t sy = py0 & ~7; sy <= py1; sy += 8)
                 for (int32_t sx = px0 & ~7; sx <= px1; sx += 32) {
@@ -542,12 +554,12 @@ __global__ __launch_bounds__(256) void k_raster_big(FrameParams P) {
                         pix[k] = 0;
                         if (px < px0 || px > px1 || py < py0 || py > py1) continue;
                         const int32_t cx = px * 256 + 128, cy = py * 256 + 128;
-                        const int32_t F0 = dy0 * (cx - X1) - dx0 * (cy - Y1);
-                        const int32_t F1 = dy1 * (cx - X2) - dx1 * (cy - Y2);
-                        const int32_t F2 = dy2 * (cx - X0) - dx2 * (cy - Y0);
+                        const int32_t F0 = __mul24(dy0, cx - X1) - __mul24(dx0, cy - Y1);
+                        const int32_t F1 = __mul24(dy1, cx - X2) - __mul24(dx1, cy - Y2);
+                        const int32_t F2 = __mul24(dy2, cx - X0) - __mul24(dx2, cy - Y0);
                         if (((F0 + b0) | (F1 + b1) | (F2 + b2)) < 0) continue;
-                        const float w1 = (float)F1 / fA, w2 = (float)F2 / fA;
-                        float z = z0 + (w1 * dz1 + w2 * dz2);
+                        const float w1 = (float)F1 * iA, w2 = (float)F2 * iA;
+                        float z = fmaf(w1, dz1, fmaf(w2, dz2, z0));
                         if (!(z < 1.0f)) continue;
                         if (z < 0.0f) z = 0.0f;
                         pix[k] = (uint32_t)(py * P.W + px);

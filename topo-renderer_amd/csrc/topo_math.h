@@ -1,9 +1,10 @@
 // topo_math.h -- arithmetic of the terrain path, frozen so that results are reproducible bit for bit.
 //
 // WGSL leaves sin/cos/normalize precision, FMA contraction and sRGB rounding to the implementation; the
-// build fixes one definition (DESIGN.md "Arithmetic spec"): IEEE binary32 +,-,*,/,sqrt, NO contraction
-// (translation units including this header are compiled with -ffp-contract=off), evaluation order as the
-// WGSL writes it, Cody-Waite + Cephes minimax sin/cos, exact-curve sRGB tables.
+// build fixes one definition (DESIGN.md "Arithmetic spec"): IEEE binary32 +,-,*,/,sqrt and fma ONLY where
+// written as fmaf() (translation units including this header are compiled with -ffp-contract=off, so the
+// compiler never fuses on its own), evaluation order as written, Cody-Waite + Cephes minimax sin/cos,
+// exact-curve sRGB tables.
 //
 // Everything here is `TOPO_HD` (host + device) so the same functions run inside the HIP kernels and,
 // for unit tests only, under g++ (tests/host_emul.cpp).  Nothing in this file touches memory it is not
@@ -55,22 +56,20 @@ TOPO_HD float bits_f(uint32_t u) {
 // WGSL radians()
 TOPO_HD float deg2rad(float d) { return d * 0.017453292519943295f; }
 
-// sin & cos of x (|x| < ~1e4): k = rint(x*2/pi); r = x - k*pi/2 in three exact-product steps;
-// Cephes sinf/cosf kernels on |r| <= pi/4; quadrant swap.
+// sin & cos of x (|x| < ~1e4): k = rint(x*2/pi); r = x - k*pi/2 in three fma steps (Cody-Waite);
+// Cephes sinf/cosf kernels on |r| <= pi/4 in fma Horner form; quadrant swap.
 TOPO_HD void sincos_f(float x, float& sn, float& cs) {
-    float k = rintf(x * 0.63661977236758134f);
-    float r = x - k * 1.5703125f;
-    r = r - k * 4.837512969970703125e-4f;
-    r = r - k * 7.54978995489188e-8f;
+    const float k = rintf(x * 0.63661977236758134f);
+    float r = fmaf(-k, 1.5703125f, x);
+    r = fmaf(-k, 4.837512969970703125e-4f, r);
+    r = fmaf(-k, 7.54978995489188e-8f, r);
     const float z = r * r;
-    float a = -1.9515295891e-4f;
-    a = a * z + 8.3321608736e-3f;
-    a = a * z + -1.6666654611e-1f;
-    const float s = r + r * z * a;
-    float b = 2.443315711809948e-5f;
-    b = b * z + -1.388731625493765e-3f;
-    b = b * z + 4.166664568298827e-2f;
-    const float c = (1.0f - 0.5f * z) + z * z * b;
+    float a = fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
+    a = fmaf(a, z, -1.6666654611e-1f);
+    const float s = fmaf(r * z, a, r);
+    float b = fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+    b = fmaf(b, z, 4.166664568298827e-2f);
+    const float c = fmaf(z * z, b, fmaf(-0.5f, z, 1.0f));
     const int q = (int)k & 3;
     const bool swap = (q & 1) != 0;
     float so = swap ? c : s;
@@ -99,15 +98,15 @@ TOPO_HD float sat(float x) { return x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x); }
 TOPO_HD uint32_t to_unorm8(float v) { return (uint32_t)floorf(sat(v) * 255.0f + 0.5f); }
 TOPO_HD float from_unorm8(uint32_t c) { return (float)c / 255.0f; }
 
-// column-major 4x4 times (x, y, z, 1)
+// column-major 4x4 times (x, y, z, 1): one fused-multiply-add chain per row (what every shader compiler emits
+// for OpMatrixTimesVector): t = m0*x; t = fma(m1, y, t); t = fma(m2, z, t); t = t + m3.
 TOPO_HD void mat4_point(const float* m, float x, float y, float z, float* o) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         float t = m[r] * x;
-        t = t + m[4 + r] * y;
-        t = t + m[8 + r] * z;
-        t = t + m[12 + r] * 1.0f;
-        o[r] = t;
+        t = fmaf(m[4 + r], y, t);
+        t = fmaf(m[8 + r], z, t);
+        o[r] = t + m[12 + r];
     }
 }
 

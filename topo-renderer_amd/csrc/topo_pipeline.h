@@ -67,9 +67,9 @@ TOPO_HD f3 vertex_normal(const TileDev& t, uint32_t packed) {
     const float nx = 2.0f * from_unorm8(packed & 255u) - 1.0f;
     const float ny = 2.0f * from_unorm8((packed >> 8) & 255u) - 1.0f;
     const float nz = 2.0f * from_unorm8((packed >> 16) & 255u) - 1.0f;
-    const float* m = t.rot;
-    return {(m[0] * nx + m[3] * ny) + m[6] * nz, (m[1] * nx + m[4] * ny) + m[7] * nz,
-            (m[2] * nx + m[5] * ny) + m[8] * nz};
+    const float* m = t.rot;   // mat * vec4(n, 0): fma chain, the zero w column drops out
+    return {fmaf(m[6], nz, fmaf(m[3], ny, m[0] * nx)), fmaf(m[7], nz, fmaf(m[4], ny, m[1] * nx)),
+            fmaf(m[8], nz, fmaf(m[5], ny, m[2] * nx))};
 }
 
 // clip -> framebuffer (WebGPU framebufferCoords), snapped.  Returns the flag.
@@ -81,10 +81,11 @@ TOPO_HD int clip_to_screen(const float clip[4], float W, float H, SVert& s) {
         s.flag = kVtxNear;
         return kVtxNear;
     }
-    const float w = clip[3];
-    const float nx = clip[0] / w, ny = clip[1] / w, nz = clip[2] / w;
-    const float xf = (0.5f * (nx + 1.0f)) * W;
-    const float yf = (0.5f * (1.0f - ny)) * H;
+    const float iw = 1.0f / clip[3];                 // perspective divide = one reciprocal + multiplies
+    const float nx = clip[0] * iw, ny = clip[1] * iw, nz = clip[2] * iw;
+    const float hw = 0.5f * W, hh = 0.5f * H;       // exact: W, H are small integers
+    const float xf = fmaf(nx, hw, hw);              // 0.5*(ndc.x + 1)*W
+    const float yf = fmaf(-ny, hh, hh);             // 0.5*(1 - ndc.y)*H
     if (!(fabsf(xf) <= 1048576.0f) || !(fabsf(yf) <= 1048576.0f)) {
         s.flag = kVtxGuard;
         return kVtxGuard;
@@ -126,7 +127,7 @@ TOPO_HD void triangle_vertices(uint32_t tri, uint32_t hm1, uint32_t vx[3], uint3
 struct TriSetup {
     int64_t ax[3], ay[3], dx[3], dy[3];   // edges e0 = v1->v2 (weight of v0), e1 = v2->v0, e2 = v0->v1
     int64_t bias[3];
-    float fA;                             // doubled area as float
+    float iA;                             // 1 / doubled area (f32 reciprocal of the exact integer)
     float z0, dz1, dz2;
     int32_t px0, px1, py0, py1;           // inclusive pixel bbox clipped to the target
 };
@@ -158,7 +159,7 @@ TOPO_HD bool triangle_setup(const SVert& s0, const SVert& s1, const SVert& s2, i
         const bool own = (ts.dy[e] > 0) || (ts.dy[e] == 0 && ts.dx[e] < 0);
         ts.bias[e] = own ? 0 : -1;
     }
-    ts.fA = (float)(-area2);
+    ts.iA = 1.0f / (float)(-area2);
     ts.z0 = s0.z; ts.dz1 = s1.z - s0.z; ts.dz2 = s2.z - s0.z;
     return true;
 }
@@ -172,10 +173,10 @@ TOPO_HD bool triangle_pixel(const TriSetup& ts, int32_t px, int32_t py, float& z
         F[e] = ts.dy[e] * (cx - ts.ax[e]) - ts.dx[e] * (cy - ts.ay[e]);
         if (F[e] + ts.bias[e] < 0) return false;
     }
-    b[0] = (float)F[0] / ts.fA;
-    b[1] = (float)F[1] / ts.fA;
-    b[2] = (float)F[2] / ts.fA;
-    float zz = ts.z0 + (b[1] * ts.dz1 + b[2] * ts.dz2);
+    b[0] = (float)F[0] * ts.iA;
+    b[1] = (float)F[1] * ts.iA;
+    b[2] = (float)F[2] * ts.iA;
+    float zz = fmaf(b[1], ts.dz1, fmaf(b[2], ts.dz2, ts.z0));
     if (!(zz < 1.0f)) return false;
     if (zz < 0.0f) zz = 0.0f;
     z = zz;
@@ -226,14 +227,15 @@ TOPO_HD int clip_near(const VFull v[3], VFull out[4]) {
 
 // ---- perspective-correct varyings --------------------------------------------------------------------
 TOPO_HD void interpolate(const VFull& v0, const VFull& v1, const VFull& v2, const float b[3], f3& wpos, f3& wnrm) {
-    const float q0 = b[0] / v0.clip[3], q1 = b[1] / v1.clip[3], q2 = b[2] / v2.clip[3];
-    const float qs = (q0 + q1) + q2;
-    wpos.x = ((v0.wpos.x * q0 + v1.wpos.x * q1) + v2.wpos.x * q2) / qs;
-    wpos.y = ((v0.wpos.y * q0 + v1.wpos.y * q1) + v2.wpos.y * q2) / qs;
-    wpos.z = ((v0.wpos.z * q0 + v1.wpos.z * q1) + v2.wpos.z * q2) / qs;
-    wnrm.x = ((v0.wnrm.x * q0 + v1.wnrm.x * q1) + v2.wnrm.x * q2) / qs;
-    wnrm.y = ((v0.wnrm.y * q0 + v1.wnrm.y * q1) + v2.wnrm.y * q2) / qs;
-    wnrm.z = ((v0.wnrm.z * q0 + v1.wnrm.z * q1) + v2.wnrm.z * q2) / qs;
+    // q_i = b_i * (1/w_i); a = (a0*q0 + a1*q1 + a2*q2) * (1 / (q0+q1+q2)), sums as fma chains
+    const float q0 = b[0] * (1.0f / v0.clip[3]), q1 = b[1] * (1.0f / v1.clip[3]), q2 = b[2] * (1.0f / v2.clip[3]);
+    const float iq = 1.0f / ((q0 + q1) + q2);
+    wpos.x = fmaf(v2.wpos.x, q2, fmaf(v1.wpos.x, q1, v0.wpos.x * q0)) * iq;
+    wpos.y = fmaf(v2.wpos.y, q2, fmaf(v1.wpos.y, q1, v0.wpos.y * q0)) * iq;
+    wpos.z = fmaf(v2.wpos.z, q2, fmaf(v1.wpos.z, q1, v0.wpos.z * q0)) * iq;
+    wnrm.x = fmaf(v2.wnrm.x, q2, fmaf(v1.wnrm.x, q1, v0.wnrm.x * q0)) * iq;
+    wnrm.y = fmaf(v2.wnrm.y, q2, fmaf(v1.wnrm.y, q1, v0.wnrm.y * q0)) * iq;
+    wnrm.z = fmaf(v2.wnrm.z, q2, fmaf(v1.wnrm.z, q1, v0.wnrm.z * q0)) * iq;
 }
 
 // Full vs_main for vertex (vx,vy) of tile t under view v.
