@@ -67,7 +67,8 @@ TerrainRenderer::~TerrainRenderer() {
         (void)hipFree(kv.second.d_normals);
         (void)hipFree(kv.second.d_minmax);
     }
-    void* bufs[] = {d_tiles_, d_views_, d_vis_, d_work_, d_big_, d_rare_, d_counters_, d_out_rgba_, d_out_depth_};
+    void* bufs[] = {d_tiles_, d_views_, d_vis_, d_work_, d_big_, d_rare_, d_counters_, d_out_rgba_, d_out_depth_,
+                    d_edge_jobs_, d_corner_jobs_};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
     for (auto& e : ev_)
@@ -93,33 +94,55 @@ Tile* TerrainRenderer::find(int lat, int lon) {
     return it == tiles_.end() ? nullptr : &it->second;
 }
 
-// The compute-pass orchestration of add_terrain (terrain_renderer.rs:192-347): interior normals of the
-// new tile, then a seam pass for each loaded edge neighbour and a corner pass for each complete 2x2 block,
-// every one of them fed the NEW tile's uniforms (:275, :344).
-void TerrainRenderer::normals_for(Tile& nt, bool /*record*/) {
+// The compute-pass orchestration of add_terrain (terrain_renderer.rs:192-347) for tile `nt`: a seam pass for each
+// loaded edge neighbour and a corner pass for each complete 2x2 block, every one of them fed the NEW tile's
+// uniforms (:275, :344).  "Loaded" = inserted before `nt` (all other tiles, except while replaying).  Jobs name
+// tiles by rank (their index in the device tile table).
+void TerrainRenderer::collect_jobs(const Tile& nt, const std::map<GeoKey, uint32_t>& rank, std::vector<EdgeJob>& edges,
+                                   std::vector<CornerJob>& corners) {
     const int lat = nt.lat, lon = nt.lon;
-    launch_normals_interior(nt.dev, tile_w_, tile_h_, lds_rows_, stream_);
-    // only tiles inserted before `nt` count as loaded (all of them, except while replaying)
-    auto loaded = [&](int la, int lo) -> Tile* {
+    const uint32_t NONE = 0xFFFFFFFFu;
+    auto loaded = [&](int la, int lo) -> uint32_t {
         Tile* t = find(la, lo);
-        return (t && t != &nt && t->seq < nt.seq) ? t : nullptr;
+        return (t && t != &nt && t->seq < nt.seq) ? rank.at(geo_key(la, lo)) : NONE;
     };
-    Tile* left = loaded(lat, lon - 1);
-    Tile* right = loaded(lat, lon + 1);
-    Tile* top = loaded(lat + 1, lon);
-    Tile* bottom = loaded(lat - 1, lon);
-    Tile* top_left = loaded(lat + 1, lon - 1);
-    Tile* top_right = loaded(lat + 1, lon + 1);
-    Tile* bottom_left = loaded(lat - 1, lon - 1);
-    Tile* bottom_right = loaded(lat - 1, lon + 1);
-    if (left) launch_normals_edge(left->dev, nt.dev, nt.dev, tile_w_, tile_h_, false, stream_);
-    if (right) launch_normals_edge(nt.dev, right->dev, nt.dev, tile_w_, tile_h_, false, stream_);
-    if (top) launch_normals_edge(top->dev, nt.dev, nt.dev, tile_w_, tile_h_, true, stream_);
-    if (bottom) launch_normals_edge(nt.dev, bottom->dev, nt.dev, tile_w_, tile_h_, true, stream_);
-    if (top_left && top && left) launch_normals_corner(top_left->dev, top->dev, left->dev, nt.dev, nt.dev, tile_w_, tile_h_, stream_);
-    if (top && top_right && right) launch_normals_corner(top->dev, top_right->dev, nt.dev, right->dev, nt.dev, tile_w_, tile_h_, stream_);
-    if (left && bottom_left && bottom) launch_normals_corner(left->dev, nt.dev, bottom_left->dev, bottom->dev, nt.dev, tile_w_, tile_h_, stream_);
-    if (right && bottom && bottom_right) launch_normals_corner(nt.dev, right->dev, bottom->dev, bottom_right->dev, nt.dev, tile_w_, tile_h_, stream_);
+    const uint32_t me = rank.at(geo_key(lat, lon));
+    const uint32_t left = loaded(lat, lon - 1), right = loaded(lat, lon + 1);
+    const uint32_t top = loaded(lat + 1, lon), bottom = loaded(lat - 1, lon);
+    const uint32_t top_left = loaded(lat + 1, lon - 1), top_right = loaded(lat + 1, lon + 1);
+    const uint32_t bottom_left = loaded(lat - 1, lon - 1), bottom_right = loaded(lat - 1, lon + 1);
+    if (left != NONE) edges.push_back(EdgeJob{left, me, me, 0});
+    if (right != NONE) edges.push_back(EdgeJob{me, right, me, 0});
+    if (top != NONE) edges.push_back(EdgeJob{top, me, me, 1});
+    if (bottom != NONE) edges.push_back(EdgeJob{me, bottom, me, 1});
+    if (top_left != NONE && top != NONE && left != NONE) corners.push_back(CornerJob{top_left, top, left, me, me});
+    if (top != NONE && top_right != NONE && right != NONE) corners.push_back(CornerJob{top, top_right, me, right, me});
+    if (left != NONE && bottom_left != NONE && bottom != NONE) corners.push_back(CornerJob{left, me, bottom_left, bottom, me});
+    if (right != NONE && bottom != NONE && bottom_right != NONE) corners.push_back(CornerJob{me, right, bottom, bottom_right, me});
+}
+
+// Uploads the job lists and launches the seam and corner passes (each writes a disjoint set of texels, so one
+// launch per kind covers any number of jobs).
+int TerrainRenderer::run_seam_jobs(const std::vector<EdgeJob>& edges, const std::vector<CornerJob>& corners) {
+    if (!edges.empty()) {
+        if (int rc = ensure(&d_edge_jobs_, &cap_edge_jobs_, edges.size() * sizeof(EdgeJob))) return rc;
+        TOPO_HIP_TRY(hipMemcpyAsync(d_edge_jobs_, edges.data(), edges.size() * sizeof(EdgeJob), hipMemcpyHostToDevice, stream_));
+        launch_normals_edges((const TileDev*)d_tiles_, (const EdgeJob*)d_edge_jobs_, (uint32_t)edges.size(), tile_w_, tile_h_, stream_);
+    }
+    if (!corners.empty()) {
+        if (int rc = ensure(&d_corner_jobs_, &cap_corner_jobs_, corners.size() * sizeof(CornerJob))) return rc;
+        TOPO_HIP_TRY(hipMemcpyAsync(d_corner_jobs_, corners.data(), corners.size() * sizeof(CornerJob), hipMemcpyHostToDevice, stream_));
+        launch_normals_corners((const TileDev*)d_tiles_, (const CornerJob*)d_corner_jobs_, (uint32_t)corners.size(), tile_w_, tile_h_, stream_);
+    }
+    // the job vectors are pageable host memory: hipMemcpyAsync has staged them before returning
+    return TOPO_OK;
+}
+
+std::map<GeoKey, uint32_t> TerrainRenderer::ranks() const {
+    std::map<GeoKey, uint32_t> r;
+    uint32_t i = 0;
+    for (const auto& kv : tiles_) r[kv.first] = i++;
+    return r;
 }
 
 int TerrainRenderer::add_terrain(int32_t lat, int32_t lon, const float* heights, bool on_device, uint32_t w, uint32_t h,
@@ -145,7 +168,7 @@ int TerrainRenderer::add_terrain(int32_t lat, int32_t lon, const float* heights,
     hipError_t e = hipMalloc((void**)&t.d_normals, texels * 4);
     if (e == hipSuccess) e = hipMalloc((void**)&t.d_minmax, (size_t)bxc * byc * 2 * sizeof(float));
     if (e == hipSuccess) e = hipMemcpyAsync(t.d_heights, heights, texels * 4, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream_);
-    if (e == hipSuccess) e = hipMemsetAsync(t.d_normals, 0, texels * 4, stream_);   // zero-initialised texture
+    // (the zero-initialised normal texture: k_normals_interior writes the untouched border ring as zero)
     if (e != hipSuccess) {
         (void)hipFree(t.d_heights); (void)hipFree(t.d_normals); (void)hipFree(t.d_minmax);
         return hip_fail(e, "tile allocation/upload");
@@ -164,9 +187,17 @@ int TerrainRenderer::add_terrain(int32_t lat, int32_t lon, const float* heights,
     bool had_old = false;
     if (Tile* ex = find(lat, lon)) { old = *ex; had_old = true; tiles_.erase(geo_key(lat, lon)); }
     Tile& nt = tiles_[geo_key(lat, lon)] = t;
-    normals_for(nt, true);
     table_dirty_ = true;
-    if (!on_device) TOPO_HIP_TRY(hipStreamSynchronize(stream_));   // `heights` is only borrowed for the call
+    if (int rc = upload_tile_table()) return rc;
+    {
+        const std::map<GeoKey, uint32_t> rk = ranks();
+        std::vector<EdgeJob> edges;
+        std::vector<CornerJob> corners;
+        collect_jobs(nt, rk, edges, corners);
+        launch_normals_interior((const TileDev*)d_tiles_, rk.at(geo_key(lat, lon)), 1, tile_w_, tile_h_, lds_rows_, stream_);
+        if (int rc = run_seam_jobs(edges, corners)) return rc;
+    }
+    TOPO_HIP_TRY(hipStreamSynchronize(stream_));   // `heights` (and the job lists) are only borrowed for the call
     if (had_old) {
         TOPO_HIP_TRY(hipStreamSynchronize(stream_));
         (void)hipFree(old.d_heights); (void)hipFree(old.d_normals); (void)hipFree(old.d_minmax);
@@ -192,10 +223,18 @@ int TerrainRenderer::recompute_normals() {
     std::vector<Tile*> order;
     for (auto& kv : tiles_) order.push_back(&kv.second);
     std::sort(order.begin(), order.end(), [](Tile* a, Tile* b) { return a->seq < b->seq; });
+    if (int rc = upload_tile_table()) return rc;
+    const std::map<GeoKey, uint32_t> rk = ranks();
+    std::vector<EdgeJob> edges;
+    std::vector<CornerJob> corners;
+    for (Tile* t : order) collect_jobs(*t, rk, edges, corners);
+    if (int rc = ensure(&d_edge_jobs_, &cap_edge_jobs_, (edges.size() + 1) * sizeof(EdgeJob))) return rc;
+    if (int rc = ensure(&d_corner_jobs_, &cap_corner_jobs_, (corners.size() + 1) * sizeof(CornerJob))) return rc;
     TOPO_HIP_TRY(hipEventRecord(ev_[7], stream_));
-    for (Tile* t : order) TOPO_HIP_TRY(hipMemsetAsync(t->d_normals, 0, (size_t)tile_w_ * tile_h_ * 4, stream_));
-    for (Tile* t : order) normals_for(*t, false);
+    launch_normals_interior((const TileDev*)d_tiles_, 0, (uint32_t)order.size(), tile_w_, tile_h_, lds_rows_, stream_);
+    if (int rc = run_seam_jobs(edges, corners)) return rc;
     TOPO_HIP_TRY(hipEventRecord(ev_[8], stream_));
+    TOPO_HIP_TRY(hipStreamSynchronize(stream_));   // the job lists are locals
     load_timed_ = true;
     TOPO_HIP_TRY(hipGetLastError());
     return TOPO_OK;
@@ -280,6 +319,12 @@ int TerrainRenderer::render_views_device(uint32_t n, const topo_uniforms* views,
     p.bx_count = bxc;
     p.by_count = byc;
     p.tris_per_tile = n_tiles ? 2u * (tile_w_ - 1) * (tile_h_ - 1) : 1u;
+    {   // the cleared render target texel: Color{0, 0.71, 0.885, 1} (terrain_renderer.rs:379-384) stored as Rgba8UnormSrgb
+        float thresh[256];
+        for (int i = 0; i < 256; ++i) thresh[i] = bits_f(TOPO_SRGB_THRESH_BITS[i]);
+        p.sky_c8 = srgb_encode(thresh, 0.0f) | (srgb_encode(thresh, 0.71f) << 8) | (srgb_encode(thresh, 0.885f) << 16) |
+                   (to_unorm8(1.0f) << 24);
+    }
     last_blocks_tested_ = (uint32_t)work_cap;
 
     TOPO_HIP_TRY(hipEventRecord(ev_[0], stream_));

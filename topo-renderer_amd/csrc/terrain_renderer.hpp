@@ -63,7 +63,10 @@ class TerrainRenderer {
     int hip_fail(hipError_t e, const char* what);
     int bind_device();
     int ensure(void** p, size_t* cap, size_t need);
-    void normals_for(Tile& nt, bool record);   // the K1-K3 orchestration of add_terrain
+    void collect_jobs(const Tile& nt, const std::map<GeoKey, uint32_t>& rank, std::vector<EdgeJob>& edges,
+                      std::vector<CornerJob>& corners);   // the seam/corner orchestration of add_terrain
+    int run_seam_jobs(const std::vector<EdgeJob>& edges, const std::vector<CornerJob>& corners);
+    std::map<GeoKey, uint32_t> ranks() const;
     Tile* find(int lat, int lon);
     int upload_tile_table();
 
@@ -90,6 +93,8 @@ class TerrainRenderer {
     void* d_work_ = nullptr;     size_t cap_work_ = 0;
     void* d_big_ = nullptr;      size_t cap_big_ = 0;
     void* d_rare_ = nullptr;     size_t cap_rare_ = 0;
+    void* d_edge_jobs_ = nullptr;   size_t cap_edge_jobs_ = 0;
+    void* d_corner_jobs_ = nullptr; size_t cap_corner_jobs_ = 0;
     void* d_counters_ = nullptr; size_t cap_counters_ = 0;
     void* d_out_rgba_ = nullptr; size_t cap_out_rgba_ = 0;
     void* d_out_depth_ = nullptr; size_t cap_out_depth_ = 0;

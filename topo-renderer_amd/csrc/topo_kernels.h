@@ -45,6 +45,7 @@ struct FrameParams {
     uint32_t tile_w, tile_h;
     uint32_t bx_count, by_count;
     uint32_t tris_per_tile;
+    uint32_t sky_c8;           // the cleared render-target texel (sRGB8-encoded clear colour)
 };
 
 struct OutputParams {
@@ -57,13 +58,25 @@ struct OutputParams {
 constexpr uint32_t kStatusBigOverflow = 1u;    // big-triangle queue full: handled in-lane (slower, still exact)
 constexpr uint32_t kStatusRareOverflow = 2u;   // rare-triangle queue full: triangles were DROPPED -> the frame is invalid
 
-// load phase (add_terrain)
+// load phase (add_terrain).  Every pass of the reference's add_terrain writes a disjoint set of texels (interior
+// / one seam per adjacent pair / one corner per 2x2 block), so any number of them can run in one launch each;
+// jobs name tiles by their index in the device tile table.
+struct EdgeJob {           // compute_normals_left_right / _top_bottom (compute_normals_edge_shader.wgsl)
+    uint32_t lt, rb;       // left-or-top tile, right-or-bottom tile
+    uint32_t uni;          // the tile whose uniforms the pass reads: the one that was inserted last
+    uint32_t top_bottom;
+};
+struct CornerJob {         // compute_normals_corner (compute_normals_corner_shader.wgsl)
+    uint32_t lt, rt, lb, rb;
+    uint32_t uni;
+};
+
 void launch_block_minmax(const float* heights, float* minmax, uint32_t w, uint32_t h, hipStream_t s);
-void launch_normals_interior(const TileDev& t, uint32_t w, uint32_t h, int lds_rows, hipStream_t s);
-void launch_normals_edge(const TileDev& lt, const TileDev& rb, const TileDev& uni, uint32_t w, uint32_t h,
-                         bool top_bottom, hipStream_t s);
-void launch_normals_corner(const TileDev& lt, const TileDev& rt, const TileDev& lb, const TileDev& rb,
-                           const TileDev& uni, uint32_t w, uint32_t h, hipStream_t s);
+// interior normals of tiles[first .. first+count); also zeroes their border ring (fresh Rgba8Unorm texture)
+void launch_normals_interior(const TileDev* tiles, uint32_t first, uint32_t count, uint32_t w, uint32_t h, int lds_rows,
+                             hipStream_t s);
+void launch_normals_edges(const TileDev* tiles, const EdgeJob* jobs, uint32_t n_jobs, uint32_t w, uint32_t h, hipStream_t s);
+void launch_normals_corners(const TileDev* tiles, const CornerJob* jobs, uint32_t n_jobs, uint32_t w, uint32_t h, hipStream_t s);
 
 // frame phase (render)
 void launch_clear(const FrameParams& p, hipStream_t s);

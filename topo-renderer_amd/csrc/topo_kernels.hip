@@ -53,14 +53,18 @@ __global__ __launch_bounds__(64) void k_block_minmax(const float* __restrict__ h
     }
 }
 
-// Interior normals (compute_normals_shader.wgsl:22-51).  64 x ROWS output texels per 256-thread
-// workgroup; the (ROWS+2) x 66 height tile is staged in LDS with coalesced row loads, each texel's four
-// taps then come from LDS.  ROWS is the LDS tile-size knob swept in the benches.
+// Interior normals (compute_normals_shader.wgsl:22-51) of a batch of tiles (blockIdx.z).  64 x ROWS output
+// texels per 256-thread workgroup; the (ROWS+2) x 66 height tile is staged in LDS with coalesced row loads,
+// each texel's four taps then come from LDS; cos(latitude) is evaluated once per row.  The border ring, which
+// the shader leaves untouched (:30-33) and which is zero in a freshly created texture, is written as zero here
+// so no separate clear is needed; seam/corner passes run afterwards.  ROWS is the LDS tile-size knob.
 template <int ROWS>
-__global__ __launch_bounds__(256) void k_normals_interior(const float* __restrict__ heights, uint32_t* __restrict__ normals,
-                                                          int W, int H, float raster_y, float model_y, float scale_x,
-                                                          float scale_y) {
+__global__ __launch_bounds__(256) void k_normals_interior(const TileDev* __restrict__ tiles, uint32_t first, int W, int H) {
     __shared__ float tile[ROWS + 2][66];
+    __shared__ float s_ys[ROWS];
+    const TileDev& t = tiles[first + blockIdx.z];
+    const float* __restrict__ heights = t.heights;
+    uint32_t* __restrict__ normals = t.normals;
     const int x0 = blockIdx.x * 64, y0 = blockIdx.y * ROWS;
     for (int idx = threadIdx.x; idx < (ROWS + 2) * 66; idx += 256) {
         const int ly = idx / 66, lx = idx - ly * 66;
@@ -69,32 +73,39 @@ __global__ __launch_bounds__(256) void k_normals_interior(const float* __restric
         if (gx >= 0 && gx < W && gy >= 0 && gy < H) v = heights[(size_t)gy * W + gx];
         tile[ly][lx] = v;
     }
+    if (threadIdx.x < ROWS) {
+        const float latitude = ((float)(y0 + (int)threadIdx.x) - t.raster_y) * -t.scale_y + t.model_y;
+        s_ys[threadIdx.x] = deg2rad(t.scale_y) * kR0 * cos_f(deg2rad(latitude));
+    }
     __syncthreads();
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int gx = x0 + tx;
-    const float xs = deg2rad(scale_x) * kR0;
-    const float ys0 = deg2rad(scale_y) * kR0;
+    const float xs = deg2rad(t.scale_x) * kR0;
 #pragma unroll
     for (int r = ty; r < ROWS; r += 4) {
         const int gy = y0 + r;
-        if (gx < 1 || gy < 1 || gx >= W - 1 || gy >= H - 1) continue;
-        const float latitude = ((float)gy - raster_y) * -scale_y + model_y;
-        const float ys = ys0 * cos_f(deg2rad(latitude));
-        const uint32_t texel = normal_texel(xs, ys, tile[r][tx + 1], tile[r + 1][tx], tile[r + 1][tx + 2], tile[r + 2][tx + 1]);
+        if (gx >= W || gy >= H) continue;
+        uint32_t texel = 0;
+        if (gx >= 1 && gy >= 1 && gx < W - 1 && gy < H - 1)
+            texel = normal_texel(xs, s_ys[r], tile[r][tx + 1], tile[r + 1][tx], tile[r + 1][tx + 2], tile[r + 2][tx + 1]);
         normals[(size_t)gy * W + gx] = texel;
     }
 }
 
-// Seam normals (compute_normals_edge_shader.wgsl:25-105).  `u*` = uniforms of the newly added tile.
-__global__ __launch_bounds__(64) void k_normals_edge(const float* __restrict__ h_lt, const float* __restrict__ h_rb,
-                                                     uint32_t* __restrict__ n_lt, uint32_t* __restrict__ n_rb, int W, int H,
-                                                     float raster_y, float model_y, float scale_x, float scale_y,
-                                                     int top_bottom) {
+// Seam normals (compute_normals_edge_shader.wgsl:25-105), one job per blockIdx.y.
+__global__ __launch_bounds__(64) void k_normals_edge(const TileDev* __restrict__ tiles, const EdgeJob* __restrict__ jobs, int W, int H) {
+    const EdgeJob job = jobs[blockIdx.y];
+    const TileDev &lt = tiles[job.lt], &rb = tiles[job.rb], &u = tiles[job.uni];
+    const float* __restrict__ h_lt = lt.heights;
+    const float* __restrict__ h_rb = rb.heights;
+    uint32_t* __restrict__ n_lt = lt.normals;
+    uint32_t* __restrict__ n_rb = rb.normals;
+    const float raster_y = u.raster_y, model_y = u.model_y, scale_x = u.scale_x, scale_y = u.scale_y;
     const int id = blockIdx.x * 64 + threadIdx.x;
     if (id < 1 || id >= W - 1) return;
     const float xs = deg2rad(fabsf(scale_x)) * kR0;
     const float ys0 = deg2rad(fabsf(scale_y)) * kR0;
-    if (!top_bottom) {
+    if (!job.top_bottom) {
         if (id >= H - 1) return;   // the guard uses dimensions.x although id runs along y; see DESIGN.md
         const float latitude = ((float)id - raster_y) * -scale_y + model_y;
         const float ys = ys0 * cos_f(deg2rad(latitude));
@@ -116,25 +127,26 @@ __global__ __launch_bounds__(64) void k_normals_edge(const float* __restrict__ h
     }
 }
 
-// Shared corner of a 2x2 block (compute_normals_corner_shader.wgsl:29-63); `top` comes from the
-// bottom-right tile at (0, H-2) exactly as the shader reads it (:49).
-__global__ void k_normals_corner(const float* __restrict__ h_lt, const float* __restrict__ h_rt, const float* __restrict__ h_lb,
-                                 const float* __restrict__ h_rb, uint32_t* __restrict__ n_lt, uint32_t* __restrict__ n_rt,
-                                 uint32_t* __restrict__ n_lb, uint32_t* __restrict__ n_rb, int W, int H, float raster_y,
-                                 float model_y, float scale_x, float scale_y) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const float latitude = ((float)(H - 1) - raster_y) * -scale_y + model_y;
-    const float xs = deg2rad(fabsf(scale_x)) * kR0;
-    const float ys = deg2rad(fabsf(scale_y)) * kR0 * cos_f(deg2rad(latitude));
-    const float hT = h_rb[(size_t)(H - 2) * W + 0];
-    const float hL = h_lt[(size_t)(H - 1) * W + (W - 2)];
-    const float hR = h_rt[(size_t)(H - 1) * W + 1];
-    const float hB = h_lb[(size_t)1 * W + (W - 1)];
+// Shared corner of a 2x2 block (compute_normals_corner_shader.wgsl:29-63), one job per lane; `top` comes from
+// the bottom-right tile at (0, H-2) exactly as the shader reads it (:49).
+__global__ __launch_bounds__(64) void k_normals_corner(const TileDev* __restrict__ tiles, const CornerJob* __restrict__ jobs,
+                                                       uint32_t n_jobs, int W, int H) {
+    const uint32_t j = blockIdx.x * 64 + threadIdx.x;
+    if (j >= n_jobs) return;
+    const CornerJob job = jobs[j];
+    const TileDev &lt = tiles[job.lt], &rt = tiles[job.rt], &lb = tiles[job.lb], &rb = tiles[job.rb], &u = tiles[job.uni];
+    const float latitude = ((float)(H - 1) - u.raster_y) * -u.scale_y + u.model_y;
+    const float xs = deg2rad(fabsf(u.scale_x)) * kR0;
+    const float ys = deg2rad(fabsf(u.scale_y)) * kR0 * cos_f(deg2rad(latitude));
+    const float hT = rb.heights[(size_t)(H - 2) * W + 0];
+    const float hL = lt.heights[(size_t)(H - 1) * W + (W - 2)];
+    const float hR = rt.heights[(size_t)(H - 1) * W + 1];
+    const float hB = lb.heights[(size_t)1 * W + (W - 1)];
     const uint32_t texel = normal_texel(xs, ys, hT, hL, hR, hB);
-    n_lt[(size_t)(H - 1) * W + (W - 1)] = texel;
-    n_rt[(size_t)(H - 1) * W + 0] = texel;
-    n_lb[(size_t)0 * W + (W - 1)] = texel;
-    n_rb[0] = texel;
+    lt.normals[(size_t)(H - 1) * W + (W - 1)] = texel;
+    rt.normals[(size_t)(H - 1) * W + 0] = texel;
+    lb.normals[(size_t)0 * W + (W - 1)] = texel;
+    rb.normals[0] = texel;
 }
 
 // ======================================================================================================
@@ -445,7 +457,17 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams P) {
 #endif
                 // cell (i, j) = (x0 + lane, y0 + r - 1): a = (i,j) b = (i,j+1) c = (i+1,j) d = (i+1,j+1)
                 const SVert cc = shfl_down1(prev), d = shfl_down1(cur);
-                if (lane < ncx) {
+                // Quad-level reject (result-neutral): if all four corners are plain vertices and their common pixel
+                // box holds no pixel centre, neither triangle can produce a fragment.
+                bool live = lane < ncx;
+                if (live && (prev.flag | cur.flag | cc.flag | d.flag) == kVtxOk) {
+                    const int32_t qx0 = min(min(prev.X, cur.X), min(cc.X, d.X)), qx1 = max(max(prev.X, cur.X), max(cc.X, d.X));
+                    const int32_t qy0 = min(min(prev.Y, cur.Y), min(cc.Y, d.Y)), qy1 = max(max(prev.Y, cur.Y), max(cc.Y, d.Y));
+                    const int32_t bx0 = max((qx0 + 127) >> 8, 0), bx1 = min((qx1 - 128) >> 8, P.W - 1);
+                    const int32_t by0 = max((qy0 + 127) >> 8, 0), by1 = min((qy1 - 128) >> 8, P.H - 1);
+                    live = bx0 <= bx1 && by0 <= by1;
+                }
+                if (live) {
                     const SVert &a = prev, &b = cur;
                     const uint32_t i = x0 + lane, j = y0 + r - 1;
                     const bool even = ((i + j) & 1u) == 0;
@@ -624,23 +646,25 @@ __global__ __launch_bounds__(256) void k_resolve(FrameParams P, OutputParams O) 
     const uint64_t key = vis[(size_t)py * P.W + px];
     const float depth = bits_f((uint32_t)(key >> 32));
     const uint32_t id = (uint32_t)key;
-    // render target texel (Rgba8UnormSrgb): clear colour or the shaded winner
-    float lin[4] = {0.0f, 0.71f, 0.885f, 1.0f};          // terrain_renderer.rs:379-384
+    // render target texel (Rgba8UnormSrgb): the cleared value or the shaded winner
+    uint32_t c8 = P.sky_c8;
     if (id != kNoTri) {
+        float lin[4] = {0.0f, 0.71f, 0.885f, 1.0f};
         const uint32_t draw = id >> 1, fan = id & 1u;
         const uint32_t rank = draw / P.tris_per_tile, tri = draw - rank * P.tris_per_tile;
         ResolvedTri r;
         float z, b[3];
-        if (resolve_triangle(P.tiles[rank], P.tile_w, P.tile_h, view, P.W, P.H, tri, fan, r) &&
-            triangle_pixel(r.ts, px, py, z, b)) {
+        // (A hand-specialised variant -- shared sin/cos per cell, LDS table for the unorm decode, int32 edge
+        // functions -- measured 7 % SLOWER than this generic form on MI355X and was dropped.)
+        if (resolve_triangle(P.tiles[rank], P.tile_w, P.tile_h, view, P.W, P.H, tri, fan, r) && triangle_pixel(r.ts, px, py, z, b)) {
             f3 wpos, wnrm;
             interpolate(r.v[0], r.v[1], r.v[2], b, wpos, wnrm);
             const f3 sun = {view.sun[0], view.sun[1], view.sun[2]};
             shade_fragment(view.view_mode, sun, view.cam_x, view.cam_y, (float)px + 0.5f, (float)py + 0.5f, wpos, wnrm, lin);
         }
+        c8 = srgb_encode(s_thresh, lin[0]) | (srgb_encode(s_thresh, lin[1]) << 8) | (srgb_encode(s_thresh, lin[2]) << 16) |
+             (to_unorm8(lin[3]) << 24);
     }
-    const uint32_t c8 = srgb_encode(s_thresh, lin[0]) | (srgb_encode(s_thresh, lin[1]) << 8) |
-                        (srgb_encode(s_thresh, lin[2]) << 16) | (to_unorm8(lin[3]) << 24);
     float ln[8];
     int k = 0;
 #pragma unroll
@@ -673,11 +697,13 @@ void launch_block_minmax(const float* heights, float* minmax, uint32_t w, uint32
     hipLaunchKernelGGL(k_block_minmax, dim3(bxc * byc), dim3(64), 0, s, heights, minmax, w, h, bxc);
 }
 
-void launch_normals_interior(const TileDev& t, uint32_t w, uint32_t h, int lds_rows, hipStream_t s) {
+void launch_normals_interior(const TileDev* tiles, uint32_t first, uint32_t count, uint32_t w, uint32_t h, int lds_rows,
+                             hipStream_t s) {
+    if (count == 0) return;
     const dim3 block(256);
-#define TOPO_K1(R)                                                                                                   \
-    hipLaunchKernelGGL(k_normals_interior<R>, dim3((w + 63) / 64, (h + (R)-1) / (R)), block, 0, s, t.heights, t.normals, \
-                       (int)w, (int)h, t.raster_y, t.model_y, t.scale_x, t.scale_y)
+#define TOPO_K1(R)                                                                                                     \
+    hipLaunchKernelGGL(k_normals_interior<R>, dim3((w + 63) / 64, (h + (R)-1) / (R), count), block, 0, s, tiles, first, \
+                       (int)w, (int)h)
     switch (lds_rows) {
         case 4: TOPO_K1(4); break;
         case 8: TOPO_K1(8); break;
@@ -688,17 +714,14 @@ void launch_normals_interior(const TileDev& t, uint32_t w, uint32_t h, int lds_r
 #undef TOPO_K1
 }
 
-void launch_normals_edge(const TileDev& lt, const TileDev& rb, const TileDev& uni, uint32_t w, uint32_t h,
-                         bool top_bottom, hipStream_t s) {
-    hipLaunchKernelGGL(k_normals_edge, dim3((w + 63) / 64), dim3(64), 0, s, lt.heights, rb.heights, lt.normals,
-                       rb.normals, (int)w, (int)h, uni.raster_y, uni.model_y, uni.scale_x, uni.scale_y, top_bottom ? 1 : 0);
+void launch_normals_edges(const TileDev* tiles, const EdgeJob* jobs, uint32_t n_jobs, uint32_t w, uint32_t h, hipStream_t s) {
+    if (n_jobs == 0) return;
+    hipLaunchKernelGGL(k_normals_edge, dim3((w + 63) / 64, n_jobs), dim3(64), 0, s, tiles, jobs, (int)w, (int)h);
 }
 
-void launch_normals_corner(const TileDev& lt, const TileDev& rt, const TileDev& lb, const TileDev& rb,
-                           const TileDev& uni, uint32_t w, uint32_t h, hipStream_t s) {
-    hipLaunchKernelGGL(k_normals_corner, dim3(1), dim3(1), 0, s, lt.heights, rt.heights, lb.heights, rb.heights,
-                       lt.normals, rt.normals, lb.normals, rb.normals, (int)w, (int)h, uni.raster_y, uni.model_y,
-                       uni.scale_x, uni.scale_y);
+void launch_normals_corners(const TileDev* tiles, const CornerJob* jobs, uint32_t n_jobs, uint32_t w, uint32_t h, hipStream_t s) {
+    if (n_jobs == 0) return;
+    hipLaunchKernelGGL(k_normals_corner, dim3((n_jobs + 63) / 64), dim3(64), 0, s, tiles, jobs, n_jobs, (int)w, (int)h);
 }
 
 void launch_clear(const FrameParams& p, hipStream_t s) {
