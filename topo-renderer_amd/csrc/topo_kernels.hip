@@ -410,7 +410,10 @@ __device__ __forceinline__ SVert shfl_down1(const SVert& v) {
 // (x0+i, row-1): its four corners are its own two vertices and lane i+1's two, fetched with wave shuffles.
 // Fragments go to a per-wave LDS list that the wave drains densely (one fragment per lane) whenever a row left
 // more than a wave's worth in it.
-__global__ __launch_bounds__(256) void k_raster(FrameParams P) {
+#ifndef TOPO_RASTER_WAVES
+#define TOPO_RASTER_WAVES 5
+#endif
+__global__ __launch_bounds__(256, TOPO_RASTER_WAVES) void k_raster(FrameParams P) {
     __shared__ FragList s_fl[4];
     uint32_t count = P.counters[0];
     if (count > P.work_cap) count = P.work_cap;
@@ -434,12 +437,18 @@ __global__ __launch_bounds__(256) void k_raster(FrameParams P) {
         sincos_f(vertex_lon(t, vcol ? vx : x0), slo, clo);
         if (lane < nrows) sincos_f(vertex_lat(t, y0 + lane), lat_s, lat_c);
         const float* hcol = t.heights + (size_t)y0 * P.tile_w + (vcol ? vx : x0);
-        float h_next = *hcol;
+        // heights are prefetched four rows ahead (a rotating register window): one 244-B row read per wave is
+        // too little to have in flight at a time
+        float h0 = hcol[0];
+        float h1 = nrows > 1 ? hcol[(size_t)1 * P.tile_w] : 0.0f;
+        float h2 = nrows > 2 ? hcol[(size_t)2 * P.tile_w] : 0.0f;
+        float h3 = nrows > 3 ? hcol[(size_t)3 * P.tile_w] : 0.0f;
         SVert prev;
         prev.X = 0; prev.Y = 0; prev.z = 0.0f; prev.flag = kVtxNear;
         for (uint32_t r = 0; r < nrows; ++r) {
-            const float h = h_next;
-            if (r + 1 < nrows) h_next = hcol[(size_t)(r + 1) * P.tile_w];
+            const float h = h0;
+            h0 = h1; h1 = h2; h2 = h3;
+            if (r + 4 < nrows) h3 = hcol[(size_t)(r + 4) * P.tile_w];
             const float sla = __shfl(lat_s, (int)r), cla = __shfl(lat_c, (int)r);
             SVert cur;
             cur.X = 0; cur.Y = 0; cur.z = 0.0f; cur.flag = kVtxNear;
