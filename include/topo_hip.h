@@ -107,6 +107,19 @@ int topo_render_views_device(topo_ctx* ctx, uint32_t n_views, const topo_uniform
                              uint32_t height, uint8_t* rgba_dev, size_t rgba_view_stride, size_t rgba_pitch,
                              float* depth_dev, size_t depth_view_stride, size_t depth_pitch);
 
+/* RenderEngine::get_visible_labels(peaks, projection, size, depth_state, depth_buffer_view)   render_engine.rs:338-396
+ * (the immediate consumer of the depth output, kept on the device so the pad_256 read-back
+ * disappears).  For each peak (ECEF f32 xyz, PeakInstance.position): project_point3 through `camera_proj`; inside
+ * the open NDC cube (|x| < 1, |y| < 1, z < 1) it maps to pixel (x_pos, y_pos) = ((0.5*(x+1)*w) as u32,
+ * (-0.5*(y-1)*h) as u32) and is visible iff dist_from_depth(z) - 10 < dist_from_depth(depth[y_pos][x_pos]).
+ * visible_out[i] = 0/1; xy_out[2i], xy_out[2i+1] = pixel (0 when not visible).  Host pointers; uses the uniforms of
+ * the last topo_update and the depth of the last topo_render (which must have been called with depth_out). */
+int topo_visible_peaks(topo_ctx* ctx, uint32_t n_peaks, const float* peaks_xyz, uint8_t* visible_out, uint32_t* xy_out);
+/* Same over caller-owned device memory (any view of a topo_render_views_device submission); asynchronous. */
+int topo_visible_peaks_device(topo_ctx* ctx, const topo_uniforms* view, uint32_t width, uint32_t height,
+                              const float* depth_dev, size_t depth_pitch, uint32_t n_peaks, const float* peaks_xyz_dev,
+                              uint8_t* visible_dev, uint32_t* xy_dev);
+
 /* Run the context's work on an existing hipStream_t (e.g. PyTorch's current stream); NULL restores the
  * context's own stream. */
 int topo_set_stream(topo_ctx* ctx, void* hip_stream);

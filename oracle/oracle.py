@@ -149,6 +149,16 @@ class OracleRenderer:
         self._check(lib().oracle_render_views(self._h, n, _p(us), _p(rgba), w * h * 4, w * 4, _p(depth), w * h * 4, w * 4, threads))
         return rgba, depth
 
+    def visible_peaks(self, peaks_xyz):
+        pk = np.ascontiguousarray(peaks_xyz, dtype=np.float32).reshape(-1, 3)
+        n = pk.shape[0]
+        vis = np.zeros(n, np.uint8)
+        xy = np.zeros((n, 2), np.uint32)
+        L = lib()
+        L.oracle_visible_peaks.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        self._check(L.oracle_visible_peaks(self._h, n, _p(pk), _p(vis), _p(xy)))
+        return vis.astype(bool), xy
+
     def read_normals(self, lat, lon, w, h):
         out = np.empty((h, w, 4), np.uint8)
         self._check(lib().oracle_read_normals(self._h, lat, lon, _p(out)))

@@ -747,6 +747,42 @@ int oracle_read_normals(void* p, int32_t lat, int32_t lon, uint8_t* out) {
     return 0;
 }
 
+/* RenderEngine::get_visible_labels: render_engine.rs:338-396, over the depth of the last oracle_render, indexed with
+ * the reference's pad_256 row pitch (:364-370).  glam Mat4::project_point3 = ((x_axis*x, y_axis*y + ., z_axis*z + .),
+ * w_axis + .) / w in f32 without fma. */
+int oracle_visible_peaks(void* p, uint32_t n, const float* peaks_xyz, uint8_t* visible, uint32_t* xy) {
+    Oracle& o = *(Oracle*)p;
+    const Frame& f = o.frame;
+    if (f.W != o.W || f.H != o.H || f.depth.empty()) { o.err = "render first"; return -1; }
+    /* the depth read buffer as the reference lays it out */
+    const uint32_t pitch = ((o.W * 4 - 1) / 256 + 1) * 256;
+    std::vector<uint8_t> buf((size_t)pitch * o.H, 0);
+    for (uint32_t y = 0; y < o.H; ++y) memcpy(&buf[(size_t)y * pitch], &f.depth[(size_t)y * o.W], (size_t)o.W * 4);
+    const float* m = o.u.camera_proj;
+    for (uint32_t i = 0; i < n; ++i) {
+        const float X = peaks_xyz[3 * i], Y = peaks_xyz[3 * i + 1], Z = peaks_xyz[3 * i + 2];
+        float res[4];
+        for (int r = 0; r < 4; ++r) res[r] = m[r] * X;
+        for (int r = 0; r < 4; ++r) res[r] = m[4 + r] * Y + res[r];
+        for (int r = 0; r < 4; ++r) res[r] = m[8 + r] * Z + res[r];
+        for (int r = 0; r < 4; ++r) res[r] = m[12 + r] + res[r];
+        const float px = res[0] / res[3], py = res[1] / res[3], pz = res[2] / res[3];
+        visible[i] = 0; xy[2 * i] = 0; xy[2 * i + 1] = 0;
+        if (px > -1.0f && px < 1.0f && py > -1.0f && py < 1.0f && pz < 1.0f) {
+            const uint32_t x_pos = (uint32_t)(0.5f * (px + 1.0f) * (float)o.W);
+            const uint32_t y_pos = (uint32_t)(-0.5f * (py - 1.0f) * (float)o.H);
+            const size_t pos = (size_t)x_pos * 4 + (size_t)y_pos * pitch;
+            if (x_pos >= o.W || pos + 4 > buf.size()) continue;    /* the reference would panic here */
+            float depth_value;
+            memcpy(&depth_value, &buf[pos], 4);
+            const float terrain_distance = dist_from_depth(depth_value);
+            const float peak_distance = dist_from_depth(pz);
+            if (peak_distance - 10.0f < terrain_distance) { visible[i] = 1; xy[2 * i] = x_pos; xy[2 * i + 1] = y_pos; }
+        }
+    }
+    return 0;
+}
+
 /* host-side helpers (glam restatement) */
 void oracle_camera_uniforms(const float eye[3], float yaw, float pitch, float fov_y, float width, float height,
                             float sun_theta_deg, float sun_phi_deg, int32_t view_mode, void* out160) {

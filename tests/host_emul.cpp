@@ -176,6 +176,17 @@ void emul_coverage_probe(uint32_t W, uint32_t H, const float xy[6], uint32_t* co
     }
 }
 
+// product's project_peak + the depth comparison, over a tightly packed depth image
+void emul_visible_peaks(const float* proj, uint32_t W, uint32_t H, const float* depth, uint32_t n, const float* peaks,
+                        uint8_t* visible, uint32_t* xy) {
+    for (uint32_t i = 0; i < n; ++i) {
+        uint32_t x_pos = 0, y_pos = 0; float pd = 0.0f; bool vis = false;
+        if (project_peak(proj, peaks[3 * i], peaks[3 * i + 1], peaks[3 * i + 2], (float)W, (float)H, x_pos, y_pos, pd) && x_pos < W && y_pos < H)
+            vis = pd - 10.0f < linear_depth(depth[(size_t)y_pos * W + x_pos]);
+        visible[i] = vis; xy[2 * i] = vis ? x_pos : 0; xy[2 * i + 1] = vis ? y_pos : 0;
+    }
+}
+
 uint64_t emul_vis_key(float z, uint32_t id) { return vis_key(z, id); }
 
 void emul_srgb_tables(float* decode, float* thresh) {

@@ -48,3 +48,19 @@ def assert_same_frame(a, b, what=""):
     if len(cm):
         msg += f"; first colour @{tuple(cm[0])} {ra[tuple(cm[0])]} vs {rb[tuple(cm[0])]}"
     assert len(dm) == 0 and len(cm) == 0, msg
+
+
+def random_peaks(sc: "Scene", n=400, seed=5):
+    """Peak positions (ECEF f32, as PeakInstance.position: background_runner.rs peak -> geometry::transform) scattered
+    over the scene, some above and some below the terrain surface."""
+    rng = np.random.default_rng(seed)
+    lats = np.array([l[0] for l in sc.locs])
+    lons = np.array([l[1] for l in sc.locs])
+    out = np.zeros((n, 3), np.float32)
+    for i in range(n):
+        la = rng.uniform(lats.min() + 0.02, lats.max() + 0.98)
+        lo = rng.uniform(lons.min() + 0.02, lons.max() + 0.98)
+        tl, to = int(math.floor(la)), int(math.floor(lo))
+        ground = T.synth.height_at(sc.heights[(tl, to)], tl, to, lo, la)
+        out[i] = T.geometry_transform(ground + rng.choice([-400.0, -30.0, 0.0, 5.0, 60.0, 800.0]), lo, la)
+    return out

@@ -89,3 +89,27 @@ def test_full_size_tile_matches_oracle(topo, orc):
     fe, fo = e.render(), o.render()
     assert_same_frame(fe, fo, "1200x1200 tile")
     assert 0.2 < float((fo[1] < 1).mean()) < 0.9
+
+
+def test_peak_visibility_matches_oracle(topo, orc):
+    # RenderEngine::get_visible_labels (render_engine.rs:338-396)
+    import ctypes as C
+    from scenes import random_peaks
+    sc = Scene(64, 2, 2, eye_dh=400.0)
+    W, H = 200, 120                                   # pad_256(4*200) = 1024 > 800: exercises the reference's row pitch
+    o = orc.OracleRenderer(W, H)
+    sc.load(o)
+    peaks = random_peaks(sc, 600)
+    seen = 0
+    for yaw, pitch in ((0, 20), (120, 35), (250, 10)):
+        u = sc.uniforms(W, H, yaw, pitch, 90, 1)
+        o.update(W, H, u, topo.post_uniforms(W, H))
+        _, depth = o.render()
+        vo, xo = o.visible_peaks(peaks)
+        ve, xe = np.zeros(len(peaks), np.uint8), np.zeros((len(peaks), 2), np.uint32)
+        proj = np.ascontiguousarray(u[:16])
+        emul.lib().emul_visible_peaks(emul._p(proj), W, H, emul._p(np.ascontiguousarray(depth)), len(peaks), emul._p(peaks), emul._p(ve), emul._p(xe))
+        assert np.array_equal(vo, ve.astype(bool)) and np.array_equal(xo, xe)
+        seen += int(vo.sum())
+        assert (xo[vo][:, 0] < W).all() and (xo[vo][:, 1] < H).all()
+    assert 10 < seen < 3 * len(peaks) - 10          # both outcomes occur

@@ -222,3 +222,28 @@ def test_big_triangle_queue_and_clipping_paths_are_exercised(topo, orc):
         assert_same_frame(g.render(), o.render(), f"coarse mesh yaw {yaw} pitch {pitch}")
         big.append(g.counters()["big_items"])
     assert max(big) > 50, big
+
+
+def test_peak_visibility_against_depth(topo, orc):
+    # get_visible_labels over the device-resident depth (render_engine.rs:338-396)
+    from scenes import random_peaks
+    sc = Scene(96, 2, 2, eye_dh=300.0)
+    W, H = 333, 200
+    g, o = both(topo, orc, W, H)
+    sc.load(g)
+    sc.load(o)
+    peaks = random_peaks(sc, 2000)
+    total = 0
+    for yaw, pitch in ((0, 20), (120, 35), (250, 10), (40, 0)):
+        u, pu = sc.uniforms(W, H, yaw, pitch, 90, 0), topo.post_uniforms(W, H)
+        g.update(W, H, u, pu)
+        o.update(W, H, u, pu)
+        assert_same_frame(g.render(), o.render(), "peaks frame")
+        vg, xg = g.visible_peaks(peaks)
+        vo, xo = o.visible_peaks(peaks)
+        assert np.array_equal(vg, vo) and np.array_equal(xg, xo)
+        total += int(vo.sum())
+    assert 20 < total < 4 * len(peaks) - 20
+    g.render(want_depth=False)
+    with pytest.raises(topo.TopoError):
+        g.visible_peaks(peaks)                        # no depth was produced by the last render

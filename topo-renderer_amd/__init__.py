@@ -93,6 +93,8 @@ def lib():
             "topo_get_counters": (C.c_int, [vp, vp]),
             "topo_read_normals": (C.c_int, [vp, i32, i32, vp]),
             "topo_probe_sincos": (C.c_int, [vp, vp, vp, vp, sz]),
+            "topo_visible_peaks": (C.c_int, [vp, u32, vp, vp, vp]),
+            "topo_visible_peaks_device": (C.c_int, [vp, vp, u32, u32, vp, sz, u32, vp, vp, vp]),
             "topo_camera_uniforms": (None, [vp, f32, f32, f32, f32, f32, f32, f32, i32, vp]),
             "topo_terrain_uniforms": (None, [vp, vp, vp, u32, u32, vp]),
             "topo_geometry_transform": (None, [f32, f32, f32, vp]),
@@ -271,6 +273,21 @@ class TerrainRenderer:
         out = np.empty((h, w, 4), np.uint8)
         self._check(lib().topo_read_normals(self._h, lat_deg, lon_deg, _p(out)))
         return out
+
+    # RenderEngine::get_visible_labels                                       render_engine.rs:338-396
+    def visible_peaks(self, peaks_xyz: np.ndarray):
+        """peaks (n,3) f32 ECEF -> (visible (n,) bool, xy (n,2) u32) against the depth of the last render()."""
+        pk = np.ascontiguousarray(peaks_xyz, dtype=np.float32).reshape(-1, 3)
+        n = pk.shape[0]
+        vis = np.zeros(n, np.uint8)
+        xy = np.zeros((n, 2), np.uint32)
+        self._check(lib().topo_visible_peaks(self._h, n, _p(pk), _p(vis), _p(xy)))
+        return vis.astype(bool), xy
+
+    def visible_peaks_device(self, uniforms, width, height, depth_ptr, depth_pitch, n, peaks_ptr, visible_ptr, xy_ptr):
+        u = np.ascontiguousarray(uniforms).view(np.uint8)
+        self._check(lib().topo_visible_peaks_device(self._h, _p(u), width, height, C.c_void_p(depth_ptr), depth_pitch, n,
+                                                    C.c_void_p(peaks_ptr), C.c_void_p(visible_ptr), C.c_void_p(xy_ptr)))
 
     def probe_sincos(self, x: np.ndarray):
         x = np.ascontiguousarray(x, dtype=np.float32)

@@ -68,7 +68,7 @@ TerrainRenderer::~TerrainRenderer() {
         (void)hipFree(kv.second.d_minmax);
     }
     void* bufs[] = {d_tiles_, d_views_, d_vis_, d_work_, d_big_, d_rare_, d_counters_, d_out_rgba_, d_out_depth_,
-                    d_edge_jobs_, d_corner_jobs_};
+                    d_edge_jobs_, d_corner_jobs_, d_peaks_, d_proj_};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
     for (auto& e : ev_)
@@ -369,6 +369,40 @@ int TerrainRenderer::render(uint8_t* rgba, size_t rgba_pitch, float* depth, size
     uint32_t status = 0;
     TOPO_HIP_TRY(hipMemcpy(&status, (uint32_t*)d_counters_ + 2, sizeof status, hipMemcpyDeviceToHost));
     if (status & kStatusRareOverflow) return fail(TOPO_ERR_CAPACITY, "rare-triangle queue overflowed: frame incomplete");
+    have_depth_ = depth != nullptr;
+    depth_w_ = W_;
+    depth_h_ = H_;
+    return TOPO_OK;
+}
+
+// RenderEngine::get_visible_labels over the depth the context already holds on the device.
+int TerrainRenderer::visible_peaks_device(const topo_uniforms* view, uint32_t w, uint32_t h, const float* depth_dev, size_t depth_pitch,
+                                          uint32_t n, const float* peaks_dev, uint8_t* visible_dev, uint32_t* xy_dev) {
+    if (!view || !depth_dev || (n && (!peaks_dev || !visible_dev || !xy_dev))) return fail(TOPO_ERR_INVALID, "null argument");
+    if (int rc = bind_device()) return rc;
+    if (int rc = ensure(&d_proj_, &cap_proj_, 16 * sizeof(float))) return rc;
+    TOPO_HIP_TRY(hipMemcpyAsync(d_proj_, view->camera_proj, 16 * sizeof(float), hipMemcpyHostToDevice, stream_));
+    launch_visible_peaks((const float*)d_proj_, w, h, depth_dev, depth_pitch, n, peaks_dev, visible_dev, xy_dev, stream_);
+    TOPO_HIP_TRY(hipGetLastError());
+    return TOPO_OK;
+}
+
+int TerrainRenderer::visible_peaks(uint32_t n, const float* peaks, uint8_t* visible, uint32_t* xy) {
+    if (n && (!peaks || !visible || !xy)) return fail(TOPO_ERR_INVALID, "null argument");
+    if (!have_depth_ || depth_w_ != W_ || depth_h_ != H_)
+        return fail(TOPO_ERR_INVALID, "topo_visible_peaks needs the depth of a preceding topo_render(.., depth_out, ..) at the current size");
+    if (n == 0) return TOPO_OK;
+    if (int rc = bind_device()) return rc;
+    const size_t in_b = (size_t)n * 12, xy_b = (size_t)n * 8, vis_b = ((size_t)n + 15) & ~(size_t)15;
+    if (int rc = ensure(&d_peaks_, &cap_peaks_, in_b + xy_b + vis_b)) return rc;
+    uint8_t* base = (uint8_t*)d_peaks_;
+    TOPO_HIP_TRY(hipMemcpyAsync(base, peaks, in_b, hipMemcpyHostToDevice, stream_));
+    if (int rc = visible_peaks_device(&uniforms_, W_, H_, (const float*)d_out_depth_, (size_t)W_ * 4, n, (const float*)base,
+                                      base + in_b + xy_b, (uint32_t*)(base + in_b)))
+        return rc;
+    TOPO_HIP_TRY(hipMemcpyAsync(xy, base + in_b, xy_b, hipMemcpyDeviceToHost, stream_));
+    TOPO_HIP_TRY(hipMemcpyAsync(visible, base + in_b + xy_b, n, hipMemcpyDeviceToHost, stream_));
+    TOPO_HIP_TRY(hipStreamSynchronize(stream_));
     return TOPO_OK;
 }
 

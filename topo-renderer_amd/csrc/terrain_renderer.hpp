@@ -54,6 +54,9 @@ class TerrainRenderer {
     int get_counters(uint32_t out[4]);
     int read_normals(int32_t lat, int32_t lon, uint8_t* out);
     int probe_sincos(const float* x, float* s, float* c, size_t n);
+    int visible_peaks(uint32_t n, const float* peaks, uint8_t* visible, uint32_t* xy);
+    int visible_peaks_device(const topo_uniforms* view, uint32_t w, uint32_t h, const float* depth_dev, size_t depth_pitch,
+                             uint32_t n, const float* peaks_dev, uint8_t* visible_dev, uint32_t* xy_dev);
 
     const char* last_error() const { return err_.c_str(); }
 
@@ -98,6 +101,10 @@ class TerrainRenderer {
     void* d_counters_ = nullptr; size_t cap_counters_ = 0;
     void* d_out_rgba_ = nullptr; size_t cap_out_rgba_ = 0;
     void* d_out_depth_ = nullptr; size_t cap_out_depth_ = 0;
+    void* d_peaks_ = nullptr;    size_t cap_peaks_ = 0;      // xyz in, then visible + xy out
+    void* d_proj_ = nullptr;     size_t cap_proj_ = 0;
+    bool have_depth_ = false;
+    uint32_t depth_w_ = 0, depth_h_ = 0;
     uint32_t last_blocks_tested_ = 0;
 
     std::string err_;

@@ -131,6 +131,18 @@ int topo_read_normals(topo_ctx* ctx, int32_t lat, int32_t lon, uint8_t* out) {
     TOPO_CALL(ctx->r->read_normals(lat, lon, out));
 }
 
+int topo_visible_peaks(topo_ctx* ctx, uint32_t n_peaks, const float* peaks_xyz, uint8_t* visible_out, uint32_t* xy_out) {
+    TOPO_GUARD(ctx);
+    TOPO_CALL(ctx->r->visible_peaks(n_peaks, peaks_xyz, visible_out, xy_out));
+}
+
+int topo_visible_peaks_device(topo_ctx* ctx, const topo_uniforms* view, uint32_t width, uint32_t height, const float* depth_dev,
+                              size_t depth_pitch, uint32_t n_peaks, const float* peaks_xyz_dev, uint8_t* visible_dev,
+                              uint32_t* xy_dev) {
+    TOPO_GUARD(ctx);
+    TOPO_CALL(ctx->r->visible_peaks_device(view, width, height, depth_dev, depth_pitch, n_peaks, peaks_xyz_dev, visible_dev, xy_dev));
+}
+
 int topo_probe_sincos(topo_ctx* ctx, const float* x, float* s, float* c, size_t n) {
     TOPO_GUARD(ctx);
     TOPO_CALL(ctx->r->probe_sincos(x, s, c, n));

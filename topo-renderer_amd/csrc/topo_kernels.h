@@ -86,6 +86,10 @@ void launch_raster_rare(const FrameParams& p, hipStream_t s);
 void launch_raster_big(const FrameParams& p, hipStream_t s);
 void launch_resolve(const FrameParams& p, const OutputParams& o, hipStream_t s);
 
+// depth consumer (RenderEngine::get_visible_labels, render_engine.rs:338-396)
+void launch_visible_peaks(const float* proj16_dev, uint32_t w, uint32_t h, const float* depth, size_t depth_pitch, uint32_t n,
+                          const float* peaks_xyz, uint8_t* visible, uint32_t* xy, hipStream_t s);
+
 // unit-test probes
 void launch_probe_sincos(const float* x, float* s, float* c, size_t n, hipStream_t st);
 

@@ -690,6 +690,26 @@ __global__ __launch_bounds__(256) void k_resolve(FrameParams P, OutputParams O) 
                                   (size_t)py * O.depth_pitch + (size_t)px * 4) = depth;
 }
 
+// One lane per peak: project, one depth lookup, one comparison (render_engine.rs:338-396).
+__global__ __launch_bounds__(256) void k_visible_peaks(const float* __restrict__ proj, uint32_t w, uint32_t h,
+                                                       const float* __restrict__ depth, size_t depth_pitch, uint32_t n,
+                                                       const float* __restrict__ peaks, uint8_t* __restrict__ visible,
+                                                       uint32_t* __restrict__ xy) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t x_pos = 0, y_pos = 0;
+    float peak_dist = 0.0f;
+    bool vis = false;
+    if (project_peak(proj, peaks[3 * i], peaks[3 * i + 1], peaks[3 * i + 2], (float)w, (float)h, x_pos, y_pos, peak_dist) &&
+        x_pos < w && y_pos < h) {       // the reference's buffer lookup would panic outside ("Failed depth buffer lookup")
+        const float d = *reinterpret_cast<const float*>(reinterpret_cast<const uint8_t*>(depth) + (size_t)y_pos * depth_pitch + (size_t)x_pos * 4);
+        vis = peak_dist - 10.0f < linear_depth(d);
+    }
+    visible[i] = vis ? 1 : 0;
+    xy[2 * i] = vis ? x_pos : 0u;
+    xy[2 * i + 1] = vis ? y_pos : 0u;
+}
+
 __global__ void k_probe_sincos(const float* x, float* s, float* c, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) sincos_f(x[i], s[i], c[i]);
@@ -761,6 +781,13 @@ void launch_raster_big(const FrameParams& p, hipStream_t s) {
 
 void launch_resolve(const FrameParams& p, const OutputParams& o, hipStream_t s) {
     hipLaunchKernelGGL(k_resolve, dim3((p.W + 63) / 64, (p.H + 3) / 4, p.n_views), dim3(256), 0, s, p, o);
+}
+
+void launch_visible_peaks(const float* proj16_dev, uint32_t w, uint32_t h, const float* depth, size_t depth_pitch, uint32_t n,
+                          const float* peaks_xyz, uint8_t* visible, uint32_t* xy, hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_visible_peaks, dim3((n + 255) / 256), dim3(256), 0, s, proj16_dev, w, h, depth, depth_pitch, n, peaks_xyz,
+                       visible, xy);
 }
 
 void launch_probe_sincos(const float* x, float* s, float* c, size_t n, hipStream_t st) {

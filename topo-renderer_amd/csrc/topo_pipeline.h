@@ -287,4 +287,27 @@ TOPO_HD bool resolve_triangle(const TileDev& t, uint32_t tile_w, uint32_t tile_h
     return triangle_setup(r.s[0], r.s[1], r.s[2], W, H, r.ts);
 }
 
+// ---- peak visibility (render_engine.rs:338-396; glam Mat4::project_point3 + camera.rs:12-14) ---------------
+// This is CPU code in the reference (glam, SSE2: separate multiplies and adds, true divisions), restated as is.
+// Returns true when the peak projects inside the open NDC cube; then (x_pos, y_pos) is its pixel and peak_dist the
+// distance the reference compares (minus 10 m) with the terrain's.
+TOPO_HD bool project_peak(const float* m, float x, float y, float z, float w, float h, uint32_t& x_pos, uint32_t& y_pos,
+                          float& peak_dist) {
+    float res[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float t = m[r] * x;
+        t = m[4 + r] * y + t;
+        t = m[8 + r] * z + t;
+        res[r] = m[12 + r] + t;
+    }
+    const float px = res[0] / res[3], py = res[1] / res[3], pz = res[2] / res[3];
+    if (!(px > -1.0f && px < 1.0f && py > -1.0f && py < 1.0f && pz < 1.0f)) return false;
+    // Rust `as u32`: truncation toward zero, saturating (the operands are in [0, size) here)
+    x_pos = (uint32_t)(0.5f * (px + 1.0f) * w);
+    y_pos = (uint32_t)(-0.5f * (py - 1.0f) * h);
+    peak_dist = linear_depth(pz);
+    return true;
+}
+
 }  // namespace topo
