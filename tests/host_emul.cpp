@@ -143,8 +143,8 @@ int emul_render(const EmulTile* tiles, uint32_t n_tiles, uint32_t tile_w, uint32
         float lin[4] = {0.0f, 0.71f, 0.885f, 1.0f};
         if (id != kNoTri) {
             const uint32_t draw = id >> 1, fan = id & 1u, rank = draw / tris_per_tile, tri = draw - rank * tris_per_tile;
-            ResolvedTri r; float z, b[3];
-            if (!(resolve_triangle(td[rank], tile_w, tile_h, view, W, H, tri, fan, r) && triangle_pixel(r.ts, px, py, z, b))) return -1;
+            ResolvedTri r; float b[3];
+            if (!(resolve_vertices(td[rank], tile_w, tile_h, view, W, H, tri, fan, r) && triangle_bary(r.s[0], r.s[1], r.s[2], px, py, b))) return -1;
             f3 wpos, wnrm;
             interpolate(r.v[0], r.v[1], r.v[2], b, wpos, wnrm);
             shade_fragment(view.view_mode, {view.sun[0], view.sun[1], view.sun[2]}, view.cam_x, view.cam_y, (float)px + 0.5f,
@@ -186,6 +186,8 @@ void emul_visible_peaks(const float* proj, uint32_t W, uint32_t H, const float* 
         visible[i] = vis; xy[2 * i] = vis ? x_pos : 0; xy[2 * i + 1] = vis ? y_pos : 0;
     }
 }
+
+float emul_from_unorm8(uint32_t c) { return from_unorm8(c); }
 
 uint64_t emul_vis_key(float z, uint32_t id) { return vis_key(z, id); }
 

@@ -22,6 +22,15 @@ def test_sincos_matches_oracle_and_libm(orc):
     assert np.abs(s - np.sin(x64)).max() < 1.5e-7 and np.abs(c - np.cos(x64)).max() < 1.5e-7
 
 
+def test_from_unorm8_is_the_exact_quotient():
+    import ctypes as C
+    L = emul.lib()
+    L.emul_from_unorm8.restype = C.c_float
+    L.emul_from_unorm8.argtypes = [C.c_uint32]
+    for c in range(256):
+        assert np.float32(L.emul_from_unorm8(c)) == np.float32(c) / np.float32(255.0)
+
+
 def test_vis_key_orders_like_less_then_draw_order():
     L = emul.lib()
     import ctypes as C

@@ -665,10 +665,9 @@ __global__ __launch_bounds__(256) void k_resolve(FrameParams P, OutputParams O) 
         const uint32_t draw = id >> 1, fan = id & 1u;
         const uint32_t rank = draw / P.tris_per_tile, tri = draw - rank * P.tris_per_tile;
         ResolvedTri r;
-        float z, b[3];
-        // (A hand-specialised variant -- shared sin/cos per cell, LDS table for the unorm decode, int32 edge
-        // functions -- measured 7 % SLOWER than this generic form on MI355X and was dropped.)
-        if (resolve_triangle(P.tiles[rank], P.tile_w, P.tile_h, view, P.W, P.H, tri, fan, r) && triangle_pixel(r.ts, px, py, z, b)) {
+        float b[3];
+        if (resolve_vertices(P.tiles[rank], P.tile_w, P.tile_h, view, P.W, P.H, tri, fan, r) &&
+            triangle_bary(r.s[0], r.s[1], r.s[2], px, py, b)) {
             f3 wpos, wnrm;
             interpolate(r.v[0], r.v[1], r.v[2], b, wpos, wnrm);
             const f3 sun = {view.sun[0], view.sun[1], view.sun[2]};

@@ -183,6 +183,40 @@ TOPO_HD bool triangle_pixel(const TriSetup& ts, int32_t px, int32_t py, float& z
     return true;
 }
 
+// Barycentrics of pixel (px,py) for a triangle known to own it (the resolve pass): the same integers and the same
+// reciprocal triangle_setup/triangle_pixel produce, without the bounding box, the ownership biases or the
+// coverage test.  Small triangles (all deltas < 2^14) use 32-bit products (24-bit multiplies on the device).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TOPO_MUL24(a, b) __mul24((a), (b))
+#else
+#define TOPO_MUL24(a, b) ((a) * (b))
+#endif
+TOPO_HD bool triangle_bary(const SVert& s0, const SVert& s1, const SVert& s2, int32_t px, int32_t py, float b[3]) {
+    const int32_t X0 = s0.X, Y0 = s0.Y, X1 = s1.X, Y1 = s1.Y, X2 = s2.X, Y2 = s2.Y;
+    const int32_t cx = px * 256 + 128, cy = py * 256 + 128;
+    int32_t mnx = X0 < X1 ? X0 : X1; mnx = mnx < X2 ? mnx : X2;
+    int32_t mxx = X0 > X1 ? X0 : X1; mxx = mxx > X2 ? mxx : X2;
+    int32_t mny = Y0 < Y1 ? Y0 : Y1; mny = mny < Y2 ? mny : Y2;
+    int32_t mxy = Y0 > Y1 ? Y0 : Y1; mxy = mxy > Y2 ? mxy : Y2;
+    if (cx < mnx || cx > mxx || cy < mny || cy > mxy) return false;
+    if ((mxx - mnx) < (1 << 14) && (mxy - mny) < (1 << 14)) {
+        const int32_t area2 = TOPO_MUL24(X1 - X0, Y2 - Y0) - TOPO_MUL24(Y1 - Y0, X2 - X0);
+        if (area2 >= 0) return false;
+        const float iA = 1.0f / (float)(-area2);
+        b[0] = (float)(TOPO_MUL24(Y2 - Y1, cx - X1) - TOPO_MUL24(X2 - X1, cy - Y1)) * iA;
+        b[1] = (float)(TOPO_MUL24(Y0 - Y2, cx - X2) - TOPO_MUL24(X0 - X2, cy - Y2)) * iA;
+        b[2] = (float)(TOPO_MUL24(Y1 - Y0, cx - X0) - TOPO_MUL24(X1 - X0, cy - Y0)) * iA;
+    } else {
+        const int64_t area2 = (int64_t)(X1 - X0) * (Y2 - Y0) - (int64_t)(Y1 - Y0) * (X2 - X0);
+        if (area2 >= 0) return false;
+        const float iA = 1.0f / (float)(-area2);
+        b[0] = (float)((int64_t)(Y2 - Y1) * (cx - X1) - (int64_t)(X2 - X1) * (cy - Y1)) * iA;
+        b[1] = (float)((int64_t)(Y0 - Y2) * (cx - X2) - (int64_t)(X0 - X2) * (cy - Y2)) * iA;
+        b[2] = (float)((int64_t)(Y1 - Y0) * (cx - X0) - (int64_t)(X1 - X0) * (cy - Y0)) * iA;
+    }
+    return true;
+}
+
 TOPO_HD uint64_t vis_key(float z, uint32_t id) { return ((uint64_t)f_bits(z) << 32) | id; }
 
 // ---- near-plane clipping of one triangle -------------------------------------------------------------
@@ -261,8 +295,8 @@ struct ResolvedTri {
     SVert s[3];
     TriSetup ts;
 };
-TOPO_HD bool resolve_triangle(const TileDev& t, uint32_t tile_w, uint32_t tile_h, const ViewDev& view, int32_t W,
-                              int32_t H, uint32_t tri, uint32_t fan, ResolvedTri& r) {
+TOPO_HD bool resolve_vertices(const TileDev& t, uint32_t tile_w, uint32_t tile_h, const ViewDev& view, int32_t W, int32_t H,
+                              uint32_t tri, uint32_t fan, ResolvedTri& r) {
     uint32_t vx[3], vy[3];
     triangle_vertices(tri, tile_h - 1, vx, vy);
     r.v[0] = vertex_full(t, tile_w, view, vx[0], vy[0]);
@@ -274,7 +308,7 @@ TOPO_HD bool resolve_triangle(const TileDev& t, uint32_t tile_w, uint32_t tile_h
         if (clip_to_screen(r.v[0].clip, (float)W, (float)H, r.s[0]) != kVtxOk) return false;
         if (clip_to_screen(r.v[1].clip, (float)W, (float)H, r.s[1]) != kVtxOk) return false;
         if (clip_to_screen(r.v[2].clip, (float)W, (float)H, r.s[2]) != kVtxOk) return false;
-        return triangle_setup(r.s[0], r.s[1], r.s[2], W, H, r.ts);
+        return true;
     }
     VFull poly[4];
     const int n = clip_near(r.v, poly);
@@ -284,7 +318,12 @@ TOPO_HD bool resolve_triangle(const TileDev& t, uint32_t tile_w, uint32_t tile_h
         if (clip_to_screen(poly[k].clip, (float)W, (float)H, s[k]) != kVtxOk) return false;
     r.v[0] = poly[0]; r.v[1] = poly[fan + 1]; r.v[2] = poly[fan + 2];
     r.s[0] = s[0]; r.s[1] = s[fan + 1]; r.s[2] = s[fan + 2];
-    return triangle_setup(r.s[0], r.s[1], r.s[2], W, H, r.ts);
+    return true;
+}
+
+TOPO_HD bool resolve_triangle(const TileDev& t, uint32_t tile_w, uint32_t tile_h, const ViewDev& view, int32_t W,
+                              int32_t H, uint32_t tri, uint32_t fan, ResolvedTri& r) {
+    return resolve_vertices(t, tile_w, tile_h, view, W, H, tri, fan, r) && triangle_setup(r.s[0], r.s[1], r.s[2], W, H, r.ts);
 }
 
 // ---- peak visibility (render_engine.rs:338-396; glam Mat4::project_point3 + camera.rs:12-14) ---------------
