@@ -297,11 +297,27 @@ struct ResolvedTri {
 };
 TOPO_HD bool resolve_vertices(const TileDev& t, uint32_t tile_w, uint32_t tile_h, const ViewDev& view, int32_t W, int32_t H,
                               uint32_t tri, uint32_t fan, ResolvedTri& r) {
-    uint32_t vx[3], vy[3];
-    triangle_vertices(tri, tile_h - 1, vx, vy);
-    r.v[0] = vertex_full(t, tile_w, view, vx[0], vy[0]);
-    r.v[1] = vertex_full(t, tile_w, view, vx[1], vy[1]);
-    r.v[2] = vertex_full(t, tile_w, view, vx[2], vy[2]);
+    // the triangle's three vertices are corners of one grid cell: two distinct longitudes, two distinct latitudes,
+    // so four sin/cos pairs serve all three vertices (same function of the same input as vertex_world)
+    const uint32_t cell = tri >> 1, k = tri & 1u, hm1 = tile_h - 1;
+    const uint32_t ci = cell / hm1, cj = cell - ci * hm1;
+    const bool even = ((ci + cj) & 1u) == 0;
+    float slo0, clo0, slo1, clo1, sla0, cla0, sla1, cla1;
+    sincos_f(vertex_lon(t, ci), slo0, clo0);
+    sincos_f(vertex_lon(t, ci + 1), slo1, clo1);
+    sincos_f(vertex_lat(t, cj), sla0, cla0);
+    sincos_f(vertex_lat(t, cj + 1), sla1, cla1);
+    // corner offsets (render_buffer.rs:191-219): k=0: a, b, (even ? d : c);  k=1: d, c, (even ? a : b)
+    const uint32_t ox[3] = {k, k, 1u - k};
+    const uint32_t oy[3] = {k, 1u - k, k == 0 ? (even ? 1u : 0u) : (even ? 0u : 1u)};
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const size_t idx = (size_t)(cj + oy[q]) * tile_w + (ci + ox[q]);
+        r.v[q].wpos = world_from_sincos(t.heights[idx], oy[q] ? sla1 : sla0, oy[q] ? cla1 : cla0, ox[q] ? slo1 : slo0,
+                                        ox[q] ? clo1 : clo0);
+        r.v[q].wnrm = vertex_normal(t, t.normals[idx]);
+        mat4_point(view.proj, r.v[q].wpos.x, r.v[q].wpos.y, r.v[q].wpos.z, r.v[q].clip);
+    }
     const bool all_in = r.v[0].clip[2] >= 0.0f && r.v[1].clip[2] >= 0.0f && r.v[2].clip[2] >= 0.0f;
     if (all_in) {   // the common case, kept free of runtime-indexed arrays
         if (fan != 0) return false;
