@@ -235,28 +235,51 @@ TOPO_HD VFull lerp_vertex(const VFull& I, const VFull& O, float t) {
     return r;
 }
 
-TOPO_HD int clip_near(const VFull v[3], VFull out[4]) {
-    const bool in0 = v[0].clip[2] >= 0.0f, in1 = v[1].clip[2] >= 0.0f, in2 = v[2].clip[2] >= 0.0f;
-    const bool in[3] = {in0, in1, in2};
-    const int nin = (int)in0 + (int)in1 + (int)in2;
-    if (nin == 0) return 0;
-    if (nin == 3) {
-        out[0] = v[0]; out[1] = v[1]; out[2] = v[2];
-        return 3;
+TOPO_HD VFull clip_edge(const VFull& I, const VFull& O) {   // I inside (z_clip >= 0), O outside
+    return lerp_vertex(I, O, I.clip[2] / (I.clip[2] - O.clip[2]));
+}
+
+// Triangle number `fan` (0 or 1) of the clipped polygon, written out case by case so that nothing is indexed at
+// run time (runtime-indexed arrays live in scratch memory on the GPU).  The polygon Sutherland-Hodgman emits --
+// walk i = 0,1,2: emit v_i if inside, then the crossing of edge (i, i+1) if it crosses -- is, by inside mask:
+//   v0        : [v0, X01, X20]          v0 v1   : [v0, v1, X12, X20]
+//   v1        : [X01, v1, X12]          v1 v2   : [X01, v1, v2, X20]
+//   v2        : [X12, v2, X20]          v0 v2   : [v0, X01, X12, v2]
+// and fan k is (p0, p[k+1], p[k+2]).  Returns false if that triangle does not exist.
+TOPO_HD bool clip_near_fan(const VFull& v0, const VFull& v1, const VFull& v2, uint32_t fan, VFull& a, VFull& b, VFull& c) {
+    const uint32_t mask = (v0.clip[2] >= 0.0f ? 1u : 0u) | (v1.clip[2] >= 0.0f ? 2u : 0u) | (v2.clip[2] >= 0.0f ? 4u : 0u);
+    switch (mask) {
+        case 7u:
+            if (fan != 0) return false;
+            a = v0; b = v1; c = v2;
+            return true;
+        case 1u:
+            if (fan != 0) return false;
+            a = v0; b = clip_edge(v0, v1); c = clip_edge(v0, v2);
+            return true;
+        case 2u:
+            if (fan != 0) return false;
+            a = clip_edge(v1, v0); b = v1; c = clip_edge(v1, v2);
+            return true;
+        case 4u:
+            if (fan != 0) return false;
+            a = clip_edge(v2, v1); b = v2; c = clip_edge(v2, v0);
+            return true;
+        case 3u:   // [v0, v1, X12, X20]
+            a = v0;
+            if (fan == 0) { b = v1; c = clip_edge(v1, v2); } else { b = clip_edge(v1, v2); c = clip_edge(v0, v2); }
+            return fan < 2;
+        case 6u:   // [X01, v1, v2, X20]
+            a = clip_edge(v1, v0);
+            if (fan == 0) { b = v1; c = v2; } else { b = v2; c = clip_edge(v2, v0); }
+            return fan < 2;
+        case 5u:   // [v0, X01, X12, v2]
+            a = v0;
+            if (fan == 0) { b = clip_edge(v0, v1); c = clip_edge(v2, v1); } else { b = clip_edge(v2, v1); c = v2; }
+            return fan < 2;
+        default:
+            return false;
     }
-    int n = 0;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int j = i == 2 ? 0 : i + 1;
-        if (in[i]) out[n++] = v[i];
-        if (in[i] != in[j]) {
-            const VFull& I = in[i] ? v[i] : v[j];
-            const VFull& O = in[i] ? v[j] : v[i];
-            const float t = I.clip[2] / (I.clip[2] - O.clip[2]);
-            out[n++] = lerp_vertex(I, O, t);
-        }
-    }
-    return n;
 }
 
 // ---- perspective-correct varyings --------------------------------------------------------------------
@@ -319,21 +342,16 @@ TOPO_HD bool resolve_vertices(const TileDev& t, uint32_t tile_w, uint32_t tile_h
         mat4_point(view.proj, r.v[q].wpos.x, r.v[q].wpos.y, r.v[q].wpos.z, r.v[q].clip);
     }
     const bool all_in = r.v[0].clip[2] >= 0.0f && r.v[1].clip[2] >= 0.0f && r.v[2].clip[2] >= 0.0f;
-    if (all_in) {   // the common case, kept free of runtime-indexed arrays
-        if (fan != 0) return false;
-        if (clip_to_screen(r.v[0].clip, (float)W, (float)H, r.s[0]) != kVtxOk) return false;
-        if (clip_to_screen(r.v[1].clip, (float)W, (float)H, r.s[1]) != kVtxOk) return false;
-        if (clip_to_screen(r.v[2].clip, (float)W, (float)H, r.s[2]) != kVtxOk) return false;
-        return true;
+    if (!all_in) {   // near-plane clipping: replace the vertices by those of fan triangle `fan`
+        VFull a, b, c;
+        if (!clip_near_fan(r.v[0], r.v[1], r.v[2], fan, a, b, c)) return false;
+        r.v[0] = a; r.v[1] = b; r.v[2] = c;
+    } else if (fan != 0) {
+        return false;
     }
-    VFull poly[4];
-    const int n = clip_near(r.v, poly);
-    if (n < 3 || (int)fan + 2 >= n) return false;
-    SVert s[4];
-    for (int k = 0; k < n; ++k)
-        if (clip_to_screen(poly[k].clip, (float)W, (float)H, s[k]) != kVtxOk) return false;
-    r.v[0] = poly[0]; r.v[1] = poly[fan + 1]; r.v[2] = poly[fan + 2];
-    r.s[0] = s[0]; r.s[1] = s[fan + 1]; r.s[2] = s[fan + 2];
+    if (clip_to_screen(r.v[0].clip, (float)W, (float)H, r.s[0]) != kVtxOk) return false;
+    if (clip_to_screen(r.v[1].clip, (float)W, (float)H, r.s[1]) != kVtxOk) return false;
+    if (clip_to_screen(r.v[2].clip, (float)W, (float)H, r.s[2]) != kVtxOk) return false;
     return true;
 }
 
