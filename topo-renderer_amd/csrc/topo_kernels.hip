@@ -435,6 +435,12 @@ __global__ __launch_bounds__(256, TOPO_RASTER_WAVES) void k_raster(FrameParams P
         const uint32_t vx = x0 + lane;
         const bool vcol = lane < kVX && vx < P.tile_w;
         uint64_t* vis = P.vis + (size_t)view_idx * P.W * P.H;
+        // the view matrix, read once per block into scalar registers: left to the compiler it is re-loaded from
+        // memory every row (it cannot prove the visibility-buffer atomics do not alias it) behind an
+        // s_waitcnt vmcnt(0) that also drains the height prefetch
+        float proj[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) proj[q] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(view.proj[q])));
         if (lane == 0) fl.count = 0;
         float slo, clo, lat_s = 0.0f, lat_c = 0.0f;
         sincos_f(vertex_lon(t, vcol ? vx : x0), slo, clo);
@@ -458,7 +464,7 @@ __global__ __launch_bounds__(256, TOPO_RASTER_WAVES) void k_raster(FrameParams P
             if (vcol) {
                 const f3 p = world_from_sincos(h, sla, cla, slo, clo);
                 float clip[4];
-                mat4_point(view.proj, p.x, p.y, p.z, clip);
+                mat4_point(proj, p.x, p.y, p.z, clip);
                 clip_to_screen(clip, (float)P.W, (float)P.H, cur);
             }
 #ifdef TOPO_ABL_NOTRI            // timing ablation only: vertex transform alone
