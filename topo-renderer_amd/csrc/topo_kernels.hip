@@ -63,8 +63,8 @@ __global__ __launch_bounds__(256) void k_normals_interior(const TileDev* __restr
     __shared__ float tile[ROWS + 2][66];
     __shared__ float s_ys[ROWS];
     const TileDev& t = tiles[first + blockIdx.z];
-    const float* __restrict__ heights = t.heights;
-    uint32_t* __restrict__ normals = t.normals;
+    const auto heights = TOPO_GLOBAL_F32(t.heights);          // global, not flat, memory operations
+    const auto normals = TOPO_GLOBAL_U32_RW(t.normals);
     const int x0 = blockIdx.x * 64, y0 = blockIdx.y * ROWS;
     for (int idx = threadIdx.x; idx < (ROWS + 2) * 66; idx += 256) {
         const int ly = idx / 66, lx = idx - ly * 66;
@@ -96,10 +96,10 @@ __global__ __launch_bounds__(256) void k_normals_interior(const TileDev* __restr
 __global__ __launch_bounds__(64) void k_normals_edge(const TileDev* __restrict__ tiles, const EdgeJob* __restrict__ jobs, int W, int H) {
     const EdgeJob job = jobs[blockIdx.y];
     const TileDev &lt = tiles[job.lt], &rb = tiles[job.rb], &u = tiles[job.uni];
-    const float* __restrict__ h_lt = lt.heights;
-    const float* __restrict__ h_rb = rb.heights;
-    uint32_t* __restrict__ n_lt = lt.normals;
-    uint32_t* __restrict__ n_rb = rb.normals;
+    const auto h_lt = TOPO_GLOBAL_F32(lt.heights);
+    const auto h_rb = TOPO_GLOBAL_F32(rb.heights);
+    const auto n_lt = TOPO_GLOBAL_U32_RW(lt.normals);
+    const auto n_rb = TOPO_GLOBAL_U32_RW(rb.normals);
     const float raster_y = u.raster_y, model_y = u.model_y, scale_x = u.scale_x, scale_y = u.scale_y;
     const int id = blockIdx.x * 64 + threadIdx.x;
     if (id < 1 || id >= W - 1) return;
@@ -138,15 +138,15 @@ __global__ __launch_bounds__(64) void k_normals_corner(const TileDev* __restrict
     const float latitude = ((float)(H - 1) - u.raster_y) * -u.scale_y + u.model_y;
     const float xs = deg2rad(fabsf(u.scale_x)) * kR0;
     const float ys = deg2rad(fabsf(u.scale_y)) * kR0 * cos_f(deg2rad(latitude));
-    const float hT = rb.heights[(size_t)(H - 2) * W + 0];
-    const float hL = lt.heights[(size_t)(H - 1) * W + (W - 2)];
-    const float hR = rt.heights[(size_t)(H - 1) * W + 1];
-    const float hB = lb.heights[(size_t)1 * W + (W - 1)];
+    const float hT = TOPO_GLOBAL_F32(rb.heights)[(size_t)(H - 2) * W + 0];
+    const float hL = TOPO_GLOBAL_F32(lt.heights)[(size_t)(H - 1) * W + (W - 2)];
+    const float hR = TOPO_GLOBAL_F32(rt.heights)[(size_t)(H - 1) * W + 1];
+    const float hB = TOPO_GLOBAL_F32(lb.heights)[(size_t)1 * W + (W - 1)];
     const uint32_t texel = normal_texel(xs, ys, hT, hL, hR, hB);
-    lt.normals[(size_t)(H - 1) * W + (W - 1)] = texel;
-    rt.normals[(size_t)(H - 1) * W + 0] = texel;
-    lb.normals[(size_t)0 * W + (W - 1)] = texel;
-    rb.normals[0] = texel;
+    TOPO_GLOBAL_U32_RW(lt.normals)[(size_t)(H - 1) * W + (W - 1)] = texel;
+    TOPO_GLOBAL_U32_RW(rt.normals)[(size_t)(H - 1) * W + 0] = texel;
+    TOPO_GLOBAL_U32_RW(lb.normals)[(size_t)0 * W + (W - 1)] = texel;
+    TOPO_GLOBAL_U32_RW(rb.normals)[0] = texel;
 }
 
 // ======================================================================================================
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(256, TOPO_RASTER_WAVES) void k_raster(FrameParams P
         float slo, clo, lat_s = 0.0f, lat_c = 0.0f;
         sincos_f(vertex_lon(t, vcol ? vx : x0), slo, clo);
         if (lane < nrows) sincos_f(vertex_lat(t, y0 + lane), lat_s, lat_c);
-        const float* hcol = t.heights + (size_t)y0 * P.tile_w + (vcol ? vx : x0);
+        const auto hcol = TOPO_GLOBAL_F32(t.heights) + (size_t)y0 * P.tile_w + (vcol ? vx : x0);   // global, not flat, loads
         // heights are prefetched four rows ahead (a rotating register window): one 244-B row read per wave is
         // too little to have in flight at a time
         float h0 = hcol[0];

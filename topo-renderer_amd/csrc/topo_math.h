@@ -24,6 +24,19 @@
 
 #include "srgb_tables.h"
 
+// Tile heights / normals are reached through pointers stored in a descriptor in memory, so the compiler only
+// knows them as generic ("flat") pointers: flat loads count on both wait counters and force vmcnt(0)+lgkmcnt(0)
+// waits that drain every prefetch.  These casts tell it the truth (hipMalloc memory = global address space).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TOPO_GLOBAL_F32(p) ((const __attribute__((address_space(1))) float*)(p))
+#define TOPO_GLOBAL_U32(p) ((const __attribute__((address_space(1))) uint32_t*)(p))
+#define TOPO_GLOBAL_U32_RW(p) ((__attribute__((address_space(1))) uint32_t*)(p))
+#else
+#define TOPO_GLOBAL_F32(p) (p)
+#define TOPO_GLOBAL_U32(p) (p)
+#define TOPO_GLOBAL_U32_RW(p) (p)
+#endif
+
 namespace topo {
 
 constexpr float kR0 = 6371000.0f;    // render_shader.wgsl:1, compute_normals_shader.wgsl:1

@@ -299,8 +299,8 @@ TOPO_HD void interpolate(const VFull& v0, const VFull& v1, const VFull& v2, cons
 TOPO_HD VFull vertex_full(const TileDev& t, uint32_t tile_w, const ViewDev& v, uint32_t vx, uint32_t vy) {
     VFull o;
     const size_t idx = (size_t)vy * tile_w + vx;
-    o.wpos = vertex_world(t, vx, vy, t.heights[idx]);
-    o.wnrm = vertex_normal(t, t.normals[idx]);
+    o.wpos = vertex_world(t, vx, vy, TOPO_GLOBAL_F32(t.heights)[idx]);
+    o.wnrm = vertex_normal(t, TOPO_GLOBAL_U32(t.normals)[idx]);
     mat4_point(v.proj, o.wpos.x, o.wpos.y, o.wpos.z, o.clip);
     return o;
 }
@@ -336,9 +336,9 @@ TOPO_HD bool resolve_vertices(const TileDev& t, uint32_t tile_w, uint32_t tile_h
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
         const size_t idx = (size_t)(cj + oy[q]) * tile_w + (ci + ox[q]);
-        r.v[q].wpos = world_from_sincos(t.heights[idx], oy[q] ? sla1 : sla0, oy[q] ? cla1 : cla0, ox[q] ? slo1 : slo0,
+        r.v[q].wpos = world_from_sincos(TOPO_GLOBAL_F32(t.heights)[idx], oy[q] ? sla1 : sla0, oy[q] ? cla1 : cla0, ox[q] ? slo1 : slo0,
                                         ox[q] ? clo1 : clo0);
-        r.v[q].wnrm = vertex_normal(t, t.normals[idx]);
+        r.v[q].wnrm = vertex_normal(t, TOPO_GLOBAL_U32(t.normals)[idx]);
         mat4_point(view.proj, r.v[q].wpos.x, r.v[q].wpos.y, r.v[q].wpos.z, r.v[q].clip);
     }
     const bool all_in = r.v[0].clip[2] >= 0.0f && r.v[1].clip[2] >= 0.0f && r.v[2].clip[2] >= 0.0f;
