@@ -283,7 +283,7 @@ __device__ __forceinline__ void enqueue_rare(const FrameParams& P, uint32_t view
 // (pixel, key) pairs to an LDS list which the workgroup then drains densely, one fragment per lane, so the
 // depth pre-test loads of 256 fragments are in flight together.
 #ifndef TOPO_FRAG_CAP
-#define TOPO_FRAG_CAP 256
+#define TOPO_FRAG_CAP 128
 #endif
 constexpr uint32_t kFragCap = TOPO_FRAG_CAP;
 struct FragList {
@@ -318,33 +318,56 @@ __device__ __forceinline__ void frag_push(FragList& fl, uint64_t* __restrict__ v
     }
 }
 
-// The common case: a triangle whose three snapped vertices span < 64 px.  Everything fits int32 (|delta| < 2^14
-// so every product is < 2^28); the integers are the same ones triangle_setup/triangle_pixel compute in int64, so
-// coverage, barycentrics and depth are bit-identical.  Boxes of up to 8 rows are walked in-lane, row by row:
-// a float estimate of each edge's crossing narrows the row to its covered span (padded by a pixel either side),
-// the exact integer test then decides every pixel, so the estimate can only cost time, never change coverage.
-__device__ __forceinline__ void raster_small(const FrameParams& P, FragList& fl, uint64_t* __restrict__ vis, const SVert& s0,
-                                             const SVert& s1, const SVert& s2, uint32_t view, uint32_t id) {
+// ---- in-wave triangle compaction -------------------------------------------------------------------------
+// Far-field cells are sub-pixel: nine triangles in ten die in the early tests (back face, no pixel centre in the
+// box).  Walking the survivors' pixels in the lane that found them would leave 58 of 64 lanes idle through every
+// loop, so k_raster works in two stages: stage 1 classifies the two triangles of each lane's cell and appends the
+// survivors to a per-wave LDS list (slot = running count + rank among the pushing lanes: no atomics); whenever
+// the list holds a wave's worth, stage 2 pops 64 of them, one per lane, and walks their pixel rows.
+constexpr uint32_t kTriCap = 128;
+struct TriList {                 // structure of arrays: lane-consecutive entries hit consecutive banks
+    int32_t X0[kTriCap], Y0[kTriCap], X1[kTriCap], Y1[kTriCap], X2[kTriCap], Y2[kTriCap];
+    float z0[kTriCap], z1[kTriCap], z2[kTriCap];
+    uint32_t id[kTriCap];
+};
+
+// Stage 1.  A triangle whose three snapped vertices span < 64 px fits int32 (|delta| < 2^14, so every product is
+// < 2^28; 24-bit multiplies give the exact integers triangle_setup computes in int64).  Returns true when the
+// triangle is to be walked in-wave (front-facing, its pixel box holds a centre and is at most kInlaneRows x
+// kInlaneCols); larger boxes go to k_raster_big, >= 64 px spans to k_raster_rare.
+__device__ __forceinline__ bool classify_small(const FrameParams& P, const SVert& s0, const SVert& s1, const SVert& s2, uint32_t view,
+                                               uint32_t id) {
     const int32_t X0 = s0.X, Y0 = s0.Y, X1 = s1.X, Y1 = s1.Y, X2 = s2.X, Y2 = s2.Y;
     const int32_t mnx = min(X0, min(X1, X2)), mxx = max(X0, max(X1, X2));
     const int32_t mny = min(Y0, min(Y1, Y2)), mxy = max(Y0, max(Y1, Y2));
     if ((mxx - mnx) >= (1 << 14) || (mxy - mny) >= (1 << 14)) {
         enqueue_rare(P, view, id >> 1);
-        return;
+        return false;
     }
-    // all deltas are < 2^14 in magnitude: 24-bit multiplies (full rate) give the exact products
     const int32_t area2 = __mul24(X1 - X0, Y2 - Y0) - __mul24(Y1 - Y0, X2 - X0);
-    if (area2 >= 0) return;
-    int32_t px0 = (mnx + 127) >> 8, px1 = (mxx - 128) >> 8, py0 = (mny + 127) >> 8, py1 = (mxy - 128) >> 8;
-    px0 = max(px0, 0);
-    py0 = max(py0, 0);
-    px1 = min(px1, P.W - 1);
-    py1 = min(py1, P.H - 1);
-    if (px0 > px1 || py0 > py1) return;
+    if (area2 >= 0) return false;
+    const int32_t px0 = max((mnx + 127) >> 8, 0), px1 = min((mxx - 128) >> 8, P.W - 1);
+    const int32_t py0 = max((mny + 127) >> 8, 0), py1 = min((mxy - 128) >> 8, P.H - 1);
+    if (px0 > px1 || py0 > py1) return false;
     if (py1 - py0 >= kInlaneRows || px1 - px0 >= kInlaneCols) {
         if (!enqueue_big(P, view, id, s0, s1, s2, px0, px1, py0, py1)) enqueue_rare(P, view, id >> 1);
-        return;
+        return false;
     }
+    return true;
+}
+
+// Stage 2: walk the pixel rows of one classified triangle.  A float estimate of each edge's crossing narrows a
+// row to its covered span (padded by a pixel either side); the exact integer test then decides every pixel, so
+// the estimate can only cost time, never change coverage.  Coverage, barycentrics and depth are the values
+// triangle_pixel() gives.
+__device__ __forceinline__ void raster_rows(FragList& fl, uint64_t* __restrict__ vis, int32_t W, int32_t H, int32_t X0, int32_t Y0,
+                                            int32_t X1, int32_t Y1, int32_t X2, int32_t Y2, float z0, float z1, float z2,
+                                            uint32_t id) {
+    const int32_t mnx = min(X0, min(X1, X2)), mxx = max(X0, max(X1, X2));
+    const int32_t mny = min(Y0, min(Y1, Y2)), mxy = max(Y0, max(Y1, Y2));
+    const int32_t area2 = __mul24(X1 - X0, Y2 - Y0) - __mul24(Y1 - Y0, X2 - X0);
+    const int32_t px0 = max((mnx + 127) >> 8, 0), px1 = min((mxx - 128) >> 8, W - 1);
+    const int32_t py0 = max((mny + 127) >> 8, 0), py1 = min((mxy - 128) >> 8, H - 1);
     // edges e0 = v1->v2, e1 = v2->v0, e2 = v0->v1
     const int32_t dx0 = X2 - X1, dy0 = Y2 - Y1, dx1 = X0 - X2, dy1 = Y0 - Y2, dx2 = X1 - X0, dy2 = Y1 - Y0;
     const int32_t b0 = ((dy0 > 0) || (dy0 == 0 && dx0 < 0)) ? 0 : -1;
@@ -359,7 +382,7 @@ __device__ __forceinline__ void raster_small(const FrameParams& P, FragList& fl,
     const float i0 = m0 ? __builtin_amdgcn_rcpf((float)m0) : 0.0f, i1 = m1 ? __builtin_amdgcn_rcpf((float)m1) : 0.0f,
                 i2 = m2 ? __builtin_amdgcn_rcpf((float)m2) : 0.0f;
     const float iA = 1.0f / (float)(-area2);
-    const float z0 = s0.z, dz1 = s1.z - s0.z, dz2 = s2.z - s0.z;
+    const float dz1 = z1 - z0, dz2 = z2 - z0;
     const int32_t nx = px1 - px0;
     for (int32_t py = py0; py <= py1; ++py) {
         // conservative span [lo, hi] (relative to px0) from each edge's crossing -r/m
@@ -379,7 +402,7 @@ __device__ __forceinline__ void raster_small(const FrameParams& P, FragList& fl,
                     float z = fmaf(w1, dz1, fmaf(w2, dz2, z0));
                     if (z < 1.0f) {
                         if (z < 0.0f) z = 0.0f;
-                        frag_push(fl, vis, (uint32_t)(py * P.W + px0 + k), vis_key(z, id));
+                        frag_push(fl, vis, (uint32_t)(py * W + px0 + k), vis_key(z, id));
                     }
                 }
                 F0 += m0;
@@ -391,6 +414,38 @@ __device__ __forceinline__ void raster_small(const FrameParams& P, FragList& fl,
         r1 -= dx1 * 256;
         r2 -= dx2 * 256;
     }
+}
+
+// Append this lane's triangle (if `push`) behind the `n` entries already listed; returns the new count.  Runs in
+// wave-uniform control flow: the slot is n + the lane's rank among the pushing lanes.
+__device__ __forceinline__ uint32_t tri_push(TriList& tl, uint32_t n, bool push, const SVert& s0, const SVert& s1, const SVert& s2,
+                                             uint32_t id) {
+    const uint64_t mask = __ballot(push);
+    if (push) {
+        const uint32_t slot = n + __popcll(mask & ((1ull << (threadIdx.x & 63)) - 1ull));
+        tl.X0[slot] = s0.X; tl.Y0[slot] = s0.Y; tl.X1[slot] = s1.X; tl.Y1[slot] = s1.Y; tl.X2[slot] = s2.X; tl.Y2[slot] = s2.Y;
+        tl.z0[slot] = s0.z; tl.z1[slot] = s1.z; tl.z2[slot] = s2.z;
+        tl.id[slot] = id;
+    }
+    return n + (uint32_t)__popcll(mask);
+}
+
+// Pop up to 64 listed triangles (the newest ones), one per lane, walk them, then flush the fragment list if it
+// holds a wave's worth (or unconditionally when `flush`).  Returns the remaining count.
+__device__ __forceinline__ uint32_t tri_drain(TriList& tl, FragList& fl, uint64_t* __restrict__ vis, int32_t W, int32_t H, uint32_t n,
+                                              bool flush) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t take = min(n, 64u), base = n - take;
+    if (lane < take) {
+        const uint32_t e = base + lane;
+        raster_rows(fl, vis, W, H, tl.X0[e], tl.Y0[e], tl.X1[e], tl.Y1[e], tl.X2[e], tl.Y2[e], tl.z0[e], tl.z1[e], tl.z2[e], tl.id[e]);
+    }
+    const uint32_t nfrag = min(fl.count, kFragCap);
+    if (nfrag >= 64 || (flush && nfrag > 0)) {
+        for (uint32_t f = lane; f < nfrag; f += 64) vis_min(vis + fl.pix[f], fl.key[f]);
+        if (lane == 0) fl.count = 0;
+    }
+    return base;
 }
 
 __device__ __forceinline__ SVert shfl_down1(const SVert& v) {
@@ -415,6 +470,7 @@ __device__ __forceinline__ SVert shfl_down1(const SVert& v) {
 #endif
 __global__ __launch_bounds__(256, TOPO_RASTER_WAVES) void k_raster(FrameParams P) {
     __shared__ FragList s_fl[4];
+    __shared__ TriList s_tl[4];
     uint32_t count = P.counters[0];
     if (count > P.work_cap) count = P.work_cap;
     // the wave index is wave-uniform: say so (readfirstlane), or the compiler treats everything derived from the
@@ -422,6 +478,8 @@ __global__ __launch_bounds__(256, TOPO_RASTER_WAVES) void k_raster(FrameParams P
     // Waves stride statically over the work list (pulling chunks from an atomic cursor measured 17 % slower).
     const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     FragList& fl = s_fl[wave];
+    TriList& tl = s_tl[wave];
+    uint32_t ntri = 0;           // triangles waiting in tl (wave-uniform)
     const uint32_t wave_global = blockIdx.x * 4 + wave, wave_count = gridDim.x * 4;
     for (uint32_t item = wave_global; item < count; item += wave_count) {
         const WorkItem wi = P.work[item];
@@ -485,36 +543,37 @@ __global__ __launch_bounds__(256, TOPO_RASTER_WAVES) void k_raster(FrameParams P
                     const int32_t by0 = max((qy0 + 127) >> 8, 0), by1 = min((qy1 - 128) >> 8, P.H - 1);
                     live = bx0 <= bx1 && by0 <= by1;
                 }
-                if (live) {
-                    const SVert &a = prev, &b = cur;
-                    const uint32_t i = x0 + lane, j = y0 + r - 1;
-                    const bool even = ((i + j) & 1u) == 0;
-                    const uint32_t tri0 = (i * (P.tile_h - 1) + j) * 2;
+                const SVert &a = prev, &b = cur;
+                const uint32_t i = x0 + lane, j = y0 + r - 1;
+                const bool even = ((i + j) & 1u) == 0;
+                const uint32_t tri0 = (i * (P.tile_h - 1) + j) * 2;
 #pragma unroll
-                    for (uint32_t k = 0; k < 2; ++k) {
-                        const SVert& s0 = k == 0 ? a : d;
-                        const SVert& s1 = k == 0 ? b : cc;
-                        const SVert& s2 = k == 0 ? (even ? d : cc) : (even ? a : b);
-                        const uint32_t tri = tri0 + k;
-                        const uint32_t draw = rank * P.tris_per_tile + tri;
+                for (uint32_t k = 0; k < 2; ++k) {
+                    const SVert& s0 = k == 0 ? a : d;
+                    const SVert& s1 = k == 0 ? b : cc;
+                    const SVert& s2 = k == 0 ? (even ? d : cc) : (even ? a : b);
+                    const uint32_t draw = rank * P.tris_per_tile + tri0 + k;
+                    bool push = false;
+                    if (live) {
                         const int fg = s0.flag | s1.flag | s2.flag;
                         if (fg == kVtxOk) {
-                            raster_small(P, fl, vis, s0, s1, s2, view_idx, draw << 1);
+                            push = classify_small(P, s0, s1, s2, view_idx, draw << 1);
                         } else if (fg & kVtxNear) {
                             const int nnear = (s0.flag == kVtxNear) + (s1.flag == kVtxNear) + (s2.flag == kVtxNear);
                             if (nnear != 3) enqueue_rare(P, view_idx, draw);
                         }   // else: guard band -> primitive discarded
                     }
-                }
-                // drain once at least a wave's worth of fragments is waiting (or at the block's end)
-                const uint32_t nfrag = min(fl.count, kFragCap);
-                if (nfrag >= 64 || r + 1 == nrows) {
-                    for (uint32_t f = lane; f < nfrag; f += 64) vis_min(vis + fl.pix[f], fl.key[f]);
-                    if (lane == 0) fl.count = 0;
+                    ntri = tri_push(tl, ntri, push, s0, s1, s2, draw << 1);
+                    if (ntri >= 64) ntri = tri_drain(tl, fl, vis, P.W, P.H, ntri, false);
                 }
             }
             prev = cur;
         }
+        // block end: the list refers to this block's view, so it is emptied before the next item
+        while (ntri > 0) ntri = tri_drain(tl, fl, vis, P.W, P.H, ntri, true);
+        const uint32_t nfrag = min(fl.count, kFragCap);
+        for (uint32_t f = lane; f < nfrag; f += 64) vis_min(vis + fl.pix[f], fl.key[f]);
+        if (lane == 0) fl.count = 0;
     }
 }
 
