@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--check", action="store_true", help="verify sector 0 against the oracle (slow)")
+    ap.add_argument("--host-path", action="store_true", help="also time topo_render (host outputs, PCIe-inclusive)")
     args = ap.parse_args()
 
     import numpy as np
@@ -148,6 +149,17 @@ def main():
     roofline = {"bound": "hbm", "kernel": "k_raster", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
                 "algorithmic_bytes_per_launch": dem_bytes, "avg_launch_ms": round(kernel_ms["raster"], 4)}
+    # HBM bytes per k_raster launch from the PMC counters cannot be collected from inside this process; they are
+    # measured in separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this same command
+    # (tools/collect_hbm_pmc.sh) and read back from profiles/hbm_traffic.json when it matches the workload.
+    try:
+        with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
+            tr = json.load(f)
+        if tr.get("workload") == args.workload and tr.get("n_gpus") == world and tr.get("kernel") == "k_raster":
+            roofline["traffic"] = tr["bytes_per_launch"]
+            roofline["traffic_source"] = tr.get("source")
+    except (OSError, ValueError, KeyError):
+        pass
 
     out = {
         "metric": "panorama Mpix/s",
@@ -179,6 +191,19 @@ def main():
     # own wgpu CPU-adapter path cannot be built here) on a bounded sample, rank 0 at N=1 only.
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(T, np, locs, vlat, vlon, views, SW, PH, args.cpu_threads)
+
+    # ---- the drop-in entry point hands back HOST buffers: its PCIe-inclusive rate (never `value`)
+    if args.host_path and rank == 0 and world == 1:
+        r.set_stream(0)
+        r.update(SW, PH, views[0], T.post_uniforms(SW, PH))
+        r.render(padded_depth=True)
+        t1 = time.perf_counter()
+        for _ in range(3):
+            r.render(padded_depth=True)
+        dt = (time.perf_counter() - t1) / 3
+        out["topo_render_host_path"] = {"mpix_s": round(SW * PH / 1e6 / dt, 1), "ms": round(dt * 1e3, 3),
+                                        "what": f"one {SW}x{PH} frame through topo_render incl. the device-to-host copies of RGBA8 and "
+                                                f"pad_256-pitched depth into pageable memory"}
 
     if args.check and rank == 0:
         out["check"] = check_against_oracle(T, np, locs, views, my, mine, depth, SW, PH)
