@@ -140,6 +140,11 @@ int topo_get_timings(topo_ctx* ctx, float out_ms[TOPO_TIMING_SLOTS]);
  * (>= 64 px across or near-clipped). */
 int topo_get_counters(topo_ctx* ctx, uint32_t out[4]);
 
+/* Test hook: capacities (entries) of the big-triangle and rare-triangle queues; 0 restores the default (4 Mi each).
+ * Lets the tests drive the overflow paths: a full big queue is handled exactly (slower), a full rare queue drops
+ * triangles and makes topo_render fail with TOPO_ERR_CAPACITY. */
+int topo_debug_set_queue_caps(topo_ctx* ctx, uint32_t big_cap, uint32_t rare_cap);
+
 /* Test accessor: the tile's Rgba8Unorm normal texture, w*h*4 bytes, host pointer. */
 int topo_read_normals(topo_ctx* ctx, int32_t lat_deg, int32_t lon_deg, uint8_t* out);
 

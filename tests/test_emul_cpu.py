@@ -122,3 +122,23 @@ def test_peak_visibility_matches_oracle(topo, orc):
         seen += int(vo.sum())
         assert (xo[vo][:, 0] < W).all() and (xo[vo][:, 1] < H).all()
     assert 10 < seen < 3 * len(peaks) - 10          # both outcomes occur
+
+
+@pytest.mark.parametrize("tw,th", [(40, 30), (30, 40), (3, 3)])
+def test_non_square_tiles_match_oracle(topo, orc, tw, th):
+    W, H = 96, 64
+    e, o = emul.EmulRenderer(W, H, topo.terrain_uniforms), orc.OracleRenderer(W, H)
+    hts = {}
+    for (la, lo) in topo.synth.mosaic_locations(-1, -1, 2, 2):       # straddles the equator and the prime meridian
+        h = topo.synth_tile(la + 46, lo + 16, max(tw, th), max(tw, th))[:th, :tw].copy()
+        tr = (np.float32([0, 0]), np.float32([lo, la + 1]), np.float32([1.0 / tw, 1.0 / th]))
+        hts[(la, lo)] = h
+        e.add_terrain(la, lo, h, *tr)
+        o.add_terrain(la, lo, h, *tr)
+    for loc in hts:
+        assert np.array_equal(e.read_normals(*loc), o.read_normals(loc[0], loc[1], tw, th)), loc
+    eye = topo.geometry_transform(float(hts[(0, 0)].max()) + 900.0, 0.02, 0.03)
+    u = topo.camera_uniforms(eye, 0.4, 0.5, math.radians(90), W, H, 0.0, 0.0, 0)
+    e.update(W, H, u, topo.post_uniforms(W, H))
+    o.update(W, H, u, topo.post_uniforms(W, H))
+    assert_same_frame(e.render(), o.render(), f"{tw}x{th}")

@@ -247,3 +247,95 @@ def test_peak_visibility_against_depth(topo, orc):
     g.render(want_depth=False)
     with pytest.raises(topo.TopoError):
         g.visible_peaks(peaks)                        # no depth was produced by the last render
+
+
+def test_queue_overflow_paths(topo, orc):
+    # big-triangle queue full -> the producers rasterise in place: slower, still exact, status bit 0 set;
+    # rare-triangle queue full -> triangles would be dropped: topo_render must fail loudly.
+    sc = Scene(12, 2, 2, eye_dh=60.0)
+    W, H = 320, 240
+    g, o = both(topo, orc, W, H)
+    sc.load(g)
+    sc.load(o)
+    u, pu = sc.uniforms(W, H, 10, 35, 110, 0), topo.post_uniforms(W, H)
+    g.update(W, H, u, pu)
+    o.update(W, H, u, pu)
+    ref = o.render()
+    g.debug_set_queue_caps(16, 0)
+    assert_same_frame(g.render(), ref, "big queue overflow")
+    assert g.counters()["status"] & 1
+    g.debug_set_queue_caps(0, 2)
+    with pytest.raises(topo.TopoError) as e:
+        g.render()
+    assert e.value.code == topo.TOPO_ERR_CAPACITY
+    g.debug_set_queue_caps(0, 0)
+    assert_same_frame(g.render(), ref, "defaults restored")
+    assert g.counters()["status"] == 0
+
+
+@pytest.mark.parametrize("tw,th", [(40, 30), (30, 40), (3, 3), (61, 16), (62, 17)])
+def test_non_square_and_tiny_tiles(topo, orc, tw, th):
+    # the seam shaders guard with dimensions.x while indexing rows (edge_shader.wgsl:33); block edges at 60/15 cells
+    import math
+    W, H = 96, 64
+    g, o = both(topo, orc, W, H)
+    hts = {}
+    for (la, lo) in topo.synth.mosaic_locations(45, 15, 2, 2):
+        h = topo.synth_tile(la, lo, max(tw, th), max(tw, th))[:th, :tw].copy()
+        tr = (np.float32([0, 0]), np.float32([lo, la + 1]), np.float32([1.0 / tw, 1.0 / th]))
+        hts[(la, lo)] = h
+        g.add_terrain(la, lo, h, *tr)
+        o.add_terrain(la, lo, h, *tr)
+    for loc in hts:
+        assert np.array_equal(g.read_normals(*loc), o.read_normals(loc[0], loc[1], tw, th)), loc
+    eye = topo.geometry_transform(float(hts[(46, 16)].max()) + 900.0, 16.02, 46.03)
+    for yaw, pitch in ((20, 25), (200, 60)):
+        u = topo.camera_uniforms(eye, math.radians(yaw), math.radians(pitch), math.radians(90), W, H, 16.0, 46.0, 0)
+        g.update(W, H, u, topo.post_uniforms(W, H))
+        o.update(W, H, u, topo.post_uniforms(W, H))
+        assert_same_frame(g.render(), o.render(), f"{tw}x{th} tiles yaw {yaw}")
+
+
+def test_hemispheres_replacement_and_draw_order(topo, orc):
+    # tiles around (0, 0): GeoLocation::from_coord maps 0 to S / W, BTreeMap order is (|lat|, dir, |lon|, dir)
+    import math
+    tile, W, H = 20, 128, 96
+    g, o = both(topo, orc, W, H)
+    locs = [(0, 0), (-1, 0), (0, -1), (-1, -1), (1, 1), (1, -1)]
+    for (la, lo) in locs:
+        h = topo.synth_tile(la + 45, lo + 15, tile, tile) + np.float32(100.0 * (la + 2))
+        tr = topo.synth.tile_transform(la, lo, tile, tile)
+        g.add_terrain(la, lo, h, *tr)
+        o.add_terrain(la, lo, h, *tr)
+    # replace one tile (BTreeMap::insert on an existing key) and unload another
+    h2 = topo.synth_tile(50, 20, tile, tile)
+    g.add_terrain(0, 0, h2, *topo.synth.tile_transform(0, 0, tile, tile))
+    o.add_terrain(0, 0, h2, *topo.synth.tile_transform(0, 0, tile, tile))
+    g.unload_terrain(1, -1)
+    o.unload_terrain(1, -1)
+    g.unload_terrain(7, 7)          # removing a key that is not there is a no-op
+    for (la, lo) in locs:
+        if (la, lo) != (1, -1):
+            assert np.array_equal(g.read_normals(la, lo), o.read_normals(la, lo, tile, tile)), (la, lo)
+    eye = topo.geometry_transform(40000.0, 0.2, 0.1)
+    for yaw, pitch in ((0, 60), (140, 75), (270, 50)):
+        u = topo.camera_uniforms(eye, math.radians(yaw), math.radians(pitch), math.radians(100), W, H, 0.0, 0.0, 0)
+        g.update(W, H, u, topo.post_uniforms(W, H))
+        o.update(W, H, u, topo.post_uniforms(W, H))
+        fr = g.render()
+        assert_same_frame(fr, o.render(), f"hemispheres yaw {yaw}")
+        assert (fr[1] < 1).mean() > 0.2
+
+
+def test_eye_below_the_surface_and_far_above(topo, orc):
+    sc = Scene(64, 2, 2)
+    W, H = 160, 100
+    g, o = both(topo, orc, W, H)
+    sc.load(g)
+    sc.load(o)
+    for dh, pitch in ((-300.0, 10.0), (-300.0, -40.0), (250000.0, 89.0), (1.0e6, 89.9)):
+        eye = topo.geometry_transform(sc.ground + dh, sc.vlon, sc.vlat)
+        u = topo.camera_uniforms(eye, 0.7, np.radians(pitch), np.radians(60), W, H, sc.vlon, sc.vlat, 0)
+        g.update(W, H, u, topo.post_uniforms(W, H))
+        o.update(W, H, u, topo.post_uniforms(W, H))
+        assert_same_frame(g.render(), o.render(), f"eye dh {dh}")

@@ -89,6 +89,7 @@ def lib():
             "topo_set_stream": (C.c_int, [vp, vp]),
             "topo_synchronize": (C.c_int, [vp]),
             "topo_set_normals_lds_rows": (C.c_int, [vp, C.c_int]),
+            "topo_debug_set_queue_caps": (C.c_int, [vp, u32, u32]),
             "topo_get_timings": (C.c_int, [vp, vp]),
             "topo_get_counters": (C.c_int, [vp, vp]),
             "topo_read_normals": (C.c_int, [vp, i32, i32, vp]),
@@ -257,6 +258,9 @@ class TerrainRenderer:
 
     def set_normals_lds_rows(self, rows: int):
         self._check(lib().topo_set_normals_lds_rows(self._h, rows))
+
+    def debug_set_queue_caps(self, big_cap: int, rare_cap: int):
+        self._check(lib().topo_debug_set_queue_caps(self._h, big_cap, rare_cap))
 
     def timings(self) -> dict:
         out = np.zeros(TIMING_SLOTS, np.float32)

@@ -276,7 +276,7 @@ int TerrainRenderer::render_views_device(uint32_t n, const topo_uniforms* views,
     const uint32_t bxc = n_tiles ? (tile_w_ - 1 + kBCX - 1) / kBCX : 0, byc = n_tiles ? (tile_h_ - 1 + kBCY - 1) / kBCY : 0;
     const size_t pixels = (size_t)n * w * h;
     const size_t work_cap = (size_t)n * n_tiles * bxc * byc;
-    const size_t big_cap = 1u << 22, rare_cap = 1u << 22;
+    const size_t big_cap = big_cap_cfg_ ? big_cap_cfg_ : (1u << 22), rare_cap = rare_cap_cfg_ ? rare_cap_cfg_ : (1u << 22);
     if (work_cap >= (1ull << 32)) return fail(TOPO_ERR_CAPACITY, "too many raster blocks in one submission");
     if (int rc = ensure(&d_vis_, &cap_vis_, pixels * 8)) return rc;
     if (int rc = ensure(&d_views_, &cap_views_, n * sizeof(ViewDev))) return rc;
@@ -422,6 +422,16 @@ int TerrainRenderer::synchronize() {
 int TerrainRenderer::set_normals_lds_rows(int rows) {
     if (rows != 4 && rows != 8 && rows != 16 && rows != 32 && rows != 64) return fail(TOPO_ERR_INVALID, "lds rows must be 4, 8, 16, 32 or 64");
     lds_rows_ = rows;
+    return TOPO_OK;
+}
+
+int TerrainRenderer::set_queue_caps(uint32_t big_cap, uint32_t rare_cap) {
+    big_cap_cfg_ = big_cap;
+    rare_cap_cfg_ = rare_cap;
+    if (d_counters_) {   // the status bits are sticky across frames: a new configuration starts clean
+        if (int rc = bind_device()) return rc;
+        TOPO_HIP_TRY(hipMemsetAsync(d_counters_, 0, 16 * sizeof(uint32_t), stream_));
+    }
     return TOPO_OK;
 }
 

@@ -50,6 +50,7 @@ class TerrainRenderer {
     int set_stream(hipStream_t s);
     int synchronize();
     int set_normals_lds_rows(int rows);
+    int set_queue_caps(uint32_t big_cap, uint32_t rare_cap);
     int get_timings(float out[TOPO_TIMING_SLOTS]);
     int get_counters(uint32_t out[4]);
     int read_normals(int32_t lat, int32_t lon, uint8_t* out);
@@ -83,6 +84,7 @@ class TerrainRenderer {
     uint64_t next_seq_ = 1;
     bool table_dirty_ = true;
     int lds_rows_ = 16;
+    uint32_t big_cap_cfg_ = 0, rare_cap_cfg_ = 0;
 
     hipStream_t own_stream_ = nullptr, stream_ = nullptr;
     static constexpr int kNumEvents = 9;

@@ -116,6 +116,11 @@ int topo_set_normals_lds_rows(topo_ctx* ctx, int rows) {
     return ctx->r->set_normals_lds_rows(rows);
 }
 
+int topo_debug_set_queue_caps(topo_ctx* ctx, uint32_t big_cap, uint32_t rare_cap) {
+    TOPO_GUARD(ctx);
+    TOPO_CALL(ctx->r->set_queue_caps(big_cap, rare_cap));
+}
+
 int topo_get_timings(topo_ctx* ctx, float out_ms[TOPO_TIMING_SLOTS]) {
     TOPO_GUARD(ctx);
     TOPO_CALL(ctx->r->get_timings(out_ms));
