@@ -29,7 +29,11 @@ WORKLOADS = {
     "c2": (1, 4096, 1024),
     "c3": (5, 8192, 2048),
     "c4": (10, 16384, 4096),
+    # config 5 (throughput mode): a batch of 1024 random viewpoints over the c4 mosaic, one 4096x1024 panorama each,
+    # sharded by VIEWPOINT across the ranks (no collective).  Not the default: a parity-test / throughput case.
+    "c5": (10, 4096, 1024),
 }
+C5_VIEWPOINTS = 1024
 LAT0, LON0 = 40, 10            # mosaic SW corner
 TILE = 1200
 N_SECTORS = 8
@@ -89,6 +93,8 @@ def main():
     setup_s = time.time() - t0
     eye = T.geometry_transform(ground + 50.0, vlon, vlat)            # render_engine.rs:327
     views = T.panorama_uniforms(eye, 0.0, SW, PH, vlon, vlat, args.view_mode)
+    if args.workload == "c5":
+        return bench_batch(args, T, np, torch, dist, r, locs, deg, SW, PH, rank, world, setup_s)
 
     # ---- load phase (normals K1-K3 over resident heights), timed on its own
     load_ms = []
@@ -208,6 +214,71 @@ def main():
     if args.check and rank == 0:
         out["check"] = check_against_oracle(T, np, locs, views, my, mine, depth, SW, PH)
 
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def _splitmix64(x):
+    x = (x + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+    z = x
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    return x, z ^ (z >> 31)
+
+
+def bench_batch(args, T, np, torch, dist, r, locs, deg, SW, PH, rank, world, setup_s):
+    """BASELINE config 5: 1024 viewpoints (splitmix64 seed 0x5EED0005; lat/lon uniform in the inner 8x8 degrees, yaw uniform
+    in [0, 2pi)), 4096x1024 each = 8 sectors of 512x1024; rank g renders viewpoints [g*1024/N, (g+1)*1024/N)."""
+    state, vps = 0x5EED0005, []
+    tiles = {}
+    for _ in range(C5_VIEWPOINTS):
+        u = []
+        for _k in range(3):
+            state, z = _splitmix64(state)
+            u.append(z / 2.0 ** 64)
+        lat, lon, yaw = LAT0 + 1.0 + 8.0 * u[0], LON0 + 1.0 + 8.0 * u[1], 2.0 * math.pi * u[2]
+        key = (int(math.floor(lat)), int(math.floor(lon)))
+        if key not in tiles:
+            tiles[key] = T.synth_tile(key[0], key[1], TILE, TILE)
+        ground = T.synth.height_at(tiles[key], key[0], key[1], lon, lat)
+        vps.append((T.geometry_transform(ground + 50.0, lon, lat), yaw, lon, lat))
+    per = C5_VIEWPOINTS // world
+    mine = vps[rank * per:(rank + 1) * per]
+    sets = [T.panorama_uniforms(e, yaw, SW, PH, lon, lat, args.view_mode) for (e, yaw, lon, lat) in mine]
+    strip = torch.empty((N_SECTORS, PH, SW, 4), dtype=torch.uint8, device="cuda")
+    depth = torch.empty((N_SECTORS, PH, SW), dtype=torch.float32, device="cuda")
+
+    def step():      # one step = this rank's whole share of the batch
+        for vs in sets:
+            r.render_views_device(vs, SW, PH, strip.data_ptr(), PH * SW * 4, SW * 4, depth.data_ptr(), PH * SW * 4, SW * 4)
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(min(args.warmup, 1)):
+        step()
+    fence()
+    steps = max(1, min(args.steps, 3))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ms = 1e3 * elapsed / steps
+    out = {"metric": "panorama Mpix/s", "value": round(C5_VIEWPOINTS * N_SECTORS * SW * PH / 1e6 / (ms / 1e3), 2), "unit": "Mpix/s",
+           "n_gpus": world, "steps": steps, "warmup": min(args.warmup, 1), "ms_per_step": round(ms, 3), "higher_is_better": True,
+           "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"c5: batch of {C5_VIEWPOINTS} viewpoints over the {deg}x{deg} deg mosaic, {N_SECTORS * SW}x{PH} panorama each",
+                      "sharding": f"viewpoints, {per} per GPU, DEM replicated, no collective"},
+           "ms_per_viewpoint": round(ms / per, 4), "setup_s": round(setup_s, 1)}
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

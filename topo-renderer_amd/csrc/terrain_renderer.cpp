@@ -73,6 +73,9 @@ TerrainRenderer::~TerrainRenderer() {
         if (p) (void)hipFree(p);
     for (auto& e : ev_)
         if (e) (void)hipEventDestroy(e);
+    for (auto& e : view_ev_)
+        if (e) (void)hipEventDestroy(e);
+    if (h_views_) (void)hipHostFree(h_views_);
     if (own_stream_) (void)hipStreamDestroy(own_stream_);
 }
 
@@ -279,7 +282,7 @@ int TerrainRenderer::render_views_device(uint32_t n, const topo_uniforms* views,
     const size_t big_cap = big_cap_cfg_ ? big_cap_cfg_ : (1u << 22), rare_cap = rare_cap_cfg_ ? rare_cap_cfg_ : (1u << 22);
     if (work_cap >= (1ull << 32)) return fail(TOPO_ERR_CAPACITY, "too many raster blocks in one submission");
     if (int rc = ensure(&d_vis_, &cap_vis_, pixels * 8)) return rc;
-    if (int rc = ensure(&d_views_, &cap_views_, n * sizeof(ViewDev))) return rc;
+    if (int rc = ensure(&d_views_, &cap_views_, sizeof(ViewDev) * kMaxViewsPerSlot * kViewSlots)) return rc;
     if (int rc = ensure(&d_work_, &cap_work_, (work_cap ? work_cap : 1) * sizeof(WorkItem))) return rc;
     if (int rc = ensure(&d_big_, &cap_big_, big_cap * sizeof(BigItem))) return rc;
     if (int rc = ensure(&d_rare_, &cap_rare_, rare_cap * sizeof(RareItem))) return rc;
@@ -287,7 +290,17 @@ int TerrainRenderer::render_views_device(uint32_t n, const topo_uniforms* views,
         if (int rc = ensure(&d_counters_, &cap_counters_, 16 * sizeof(uint32_t))) return rc;
         TOPO_HIP_TRY(hipMemsetAsync(d_counters_, 0, 16 * sizeof(uint32_t), stream_));
     }
-    std::vector<ViewDev> vd(n);
+    // view constants go through a small ring of pinned staging slots, each guarded by an event, so a submission
+    // never has to wait for the stream (pageable sources would force a synchronous staging copy)
+    if (n > kMaxViewsPerSlot) return fail(TOPO_ERR_INVALID, "too many views in one submission");
+    if (!h_views_) {
+        TOPO_HIP_TRY(hipHostMalloc((void**)&h_views_, sizeof(ViewDev) * kMaxViewsPerSlot * kViewSlots));
+        for (int i = 0; i < kViewSlots; ++i) TOPO_HIP_TRY(hipEventCreateWithFlags(&view_ev_[i], hipEventDisableTiming));
+    }
+    const int slot = view_slot_;
+    view_slot_ = (view_slot_ + 1) % kViewSlots;
+    if (view_used_[slot]) TOPO_HIP_TRY(hipEventSynchronize(view_ev_[slot]));
+    ViewDev* vd = h_views_ + (size_t)slot * kMaxViewsPerSlot;
     for (uint32_t i = 0; i < n; ++i) {
         memcpy(vd[i].proj, views[i].camera_proj, sizeof vd[i].proj);
         vd[i].cam_x = views[i].camera_pos[0];
@@ -295,13 +308,15 @@ int TerrainRenderer::render_views_device(uint32_t n, const topo_uniforms* views,
         memcpy(vd[i].sun, views[i].sun_direction, sizeof vd[i].sun);
         vd[i].view_mode = views[i].view_mode;
     }
-    // pageable source: the runtime stages the bytes before hipMemcpyAsync returns
-    TOPO_HIP_TRY(hipMemcpyAsync(d_views_, vd.data(), n * sizeof(ViewDev), hipMemcpyHostToDevice, stream_));
-    TOPO_HIP_TRY(hipStreamSynchronize(stream_));
+    // each slot has its own device copy, so a later submission cannot overwrite constants a running frame reads
+    ViewDev* d_slot = (ViewDev*)d_views_ + (size_t)slot * kMaxViewsPerSlot;
+    TOPO_HIP_TRY(hipMemcpyAsync(d_slot, vd, n * sizeof(ViewDev), hipMemcpyHostToDevice, stream_));
+    TOPO_HIP_TRY(hipEventRecord(view_ev_[slot], stream_));
+    view_used_[slot] = true;
 
     FrameParams p{};
     p.tiles = (const TileDev*)d_tiles_;
-    p.views = (const ViewDev*)d_views_;
+    p.views = d_slot;
     p.vis = (uint64_t*)d_vis_;
     p.work = (WorkItem*)d_work_;
     p.counters = (uint32_t*)d_counters_;

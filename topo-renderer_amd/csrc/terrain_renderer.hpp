@@ -103,6 +103,12 @@ class TerrainRenderer {
     void* d_counters_ = nullptr; size_t cap_counters_ = 0;
     void* d_out_rgba_ = nullptr; size_t cap_out_rgba_ = 0;
     void* d_out_depth_ = nullptr; size_t cap_out_depth_ = 0;
+    static constexpr int kViewSlots = 16;
+    static constexpr uint32_t kMaxViewsPerSlot = 64;
+    ViewDev* h_views_ = nullptr;          // pinned staging ring
+    hipEvent_t view_ev_[kViewSlots] = {};
+    bool view_used_[kViewSlots] = {};
+    int view_slot_ = 0;
     void* d_peaks_ = nullptr;    size_t cap_peaks_ = 0;      // xyz in, then visible + xy out
     void* d_proj_ = nullptr;     size_t cap_proj_ = 0;
     bool have_depth_ = false;
