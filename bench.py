@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--check", action="store_true", help="verify sector 0 against the oracle (slow)")
+    ap.add_argument("--occlusion-split", type=float, default=None, help="metres; 0 disables the two-phase occlusion filter")
     ap.add_argument("--host-path", action="store_true", help="also time topo_render (host outputs, PCIe-inclusive)")
     args = ap.parse_args()
 
@@ -79,6 +80,8 @@ def main():
     t0 = time.time()
     r = T.TerrainRenderer(SW, PH, device=local_rank)
     r.set_stream(torch.cuda.current_stream().cuda_stream)
+    if args.occlusion_split is not None:
+        r.set_occlusion_split(args.occlusion_split)
     vlat, vlon = LAT0 + deg / 2 + 0.123, LON0 + deg / 2 + 0.217      # mosaic centre + (0.123, 0.217) degrees
     ground = None
     upload_s = 0.0
@@ -123,7 +126,7 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    kernel_ms = {k: 0.0 for k in ("clear", "cull", "raster", "raster_rare", "raster_big", "resolve", "total")}
+    kernel_ms = {k: 0.0 for k in ("clear", "cull", "raster", "occlusion", "raster_big", "resolve", "total")}
     t_start = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -307,15 +310,17 @@ def cpu_baseline(T, np, locs, vlat, vlon, views, SW, PH, threads):
 
 
 def check_against_oracle(T, np, locs, views, my, mine, depth, SW, PH):
+    """Every sector this rank rendered, at full size over the full mosaic, against the oracle (bit for bit)."""
     from oracle import oracle as O
     o = O.OracleRenderer(SW, PH)
     for (la, lo) in locs:
         o.add_terrain(la, lo, T.synth_tile(la, lo, TILE, TILE), *T.synth.tile_transform(la, lo, TILE, TILE))
     o.update(SW, PH, views[my[0]], T.post_uniforms(SW, PH))
-    ro, do = o.render()
-    rg, dg = mine[0].cpu().numpy(), depth[0].cpu().numpy()
-    return {"sector": my[0], "rgba_mismatch": int((ro != rg).any(axis=-1).sum()),
-            "depth_mismatch": int((do.view(np.uint32) != dg.view(np.uint32)).sum())}
+    ro, do = o.render_views([views[k] for k in my], threads=min(len(my), os.cpu_count() or 1))
+    rg, dg = mine.cpu().numpy(), depth.cpu().numpy()
+    return {"sectors": list(my), "rgba_mismatch": int((ro != rg).any(axis=-1).sum()),
+            "depth_mismatch": int((do.view(np.uint32) != dg.view(np.uint32)).sum()),
+            "terrain_fraction": round(float((do < 1).mean()), 4)}
 
 
 if __name__ == "__main__":

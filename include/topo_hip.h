@@ -128,17 +128,22 @@ int topo_synchronize(topo_ctx* ctx);
 /* LDS tile height (output rows per workgroup: 4, 8, 16, 32 or 64) of the interior-normals kernel. */
 int topo_set_normals_lds_rows(topo_ctx* ctx, int rows);
 
+/* Two-phase occlusion filter: blocks whose nearest possible view depth exceeds `metres` are rastered only if some
+ * pixel of their conservative footprint is not already covered by nearer terrain (exact: a dropped block cannot
+ * win a pixel).  Default 60 000 m; 0 turns the filter off (one phase, every frustum-surviving block rastered). */
+int topo_set_occlusion_split(topo_ctx* ctx, float metres);
+
 /* Per-kernel durations (ms, HIP events on the context's stream) of the last topo_render* call:
- * [0] clear  [1] cull  [2] raster  [3] raster_rare  [4] raster_big  [5] resolve+post  [6] total;
- * of the last topo_recompute_normals: [7] load phase.  Synchronises. */
+ * [0] clear  [1] cull  [2] raster (both phases)  [3] occlusion test  [4] raster_rare + raster_big (both phases)
+ * [5] resolve+post  [6] total; of the last topo_recompute_normals: [7] load phase.  Synchronises. */
 #define TOPO_TIMING_SLOTS 8
 int topo_get_timings(topo_ctx* ctx, float out_ms[TOPO_TIMING_SLOTS]);
 
-/* Counters of the last topo_render* call: [0] blocks rastered, [1] big-triangle items, [2] status bits
+/* Counters of the last topo_render* call: [0] near blocks rastered, [1] big-triangle items, [2] status bits
  * (bit 0: big-triangle queue overflowed -- handled in-lane, slower, still exact; bit 1: rare-triangle queue
  * overflowed -- triangles dropped, frame invalid; topo_render returns TOPO_ERR_CAPACITY), [3] rare triangles
- * (>= 64 px across or near-clipped). */
-int topo_get_counters(topo_ctx* ctx, uint32_t out[4]);
+ * (>= 64 px across or near-clipped), [4] far blocks occlusion-tested, [5] far blocks that survived the test. */
+int topo_get_counters(topo_ctx* ctx, uint32_t out[6]);
 
 /* Test hook: capacities (entries) of the big-triangle and rare-triangle queues; 0 restores the default (4 Mi each).
  * Lets the tests drive the overflow paths: a full big queue is handled exactly (slower), a full rare queue drops

@@ -29,7 +29,7 @@ TOPO_OK = 0
 TOPO_ERR_INVALID, TOPO_ERR_UNSUPPORTED, TOPO_ERR_HIP, TOPO_ERR_NOT_FOUND, TOPO_ERR_CAPACITY = -1, -2, -3, -4, -5
 FORMAT_RGBA8_UNORM_SRGB = 1
 TIMING_SLOTS = 8
-TIMING_NAMES = ("clear", "cull", "raster", "raster_rare", "raster_big", "resolve", "total", "load")
+TIMING_NAMES = ("clear", "cull", "raster", "occlusion", "raster_big", "resolve", "total", "load")
 
 NEAR, FAR = 50.0, 500000.0           # data/camera.rs:6-7
 N_SECTORS = 8                        # fixed panorama sector count
@@ -92,6 +92,7 @@ def lib():
             "topo_debug_set_queue_caps": (C.c_int, [vp, u32, u32]),
             "topo_get_timings": (C.c_int, [vp, vp]),
             "topo_get_counters": (C.c_int, [vp, vp]),
+            "topo_set_occlusion_split": (C.c_int, [vp, f32]),
             "topo_read_normals": (C.c_int, [vp, i32, i32, vp]),
             "topo_probe_sincos": (C.c_int, [vp, vp, vp, vp, sz]),
             "topo_visible_peaks": (C.c_int, [vp, u32, vp, vp, vp]),
@@ -268,9 +269,13 @@ class TerrainRenderer:
         return {k: float(v) for k, v in zip(TIMING_NAMES, out) if k != "_"}
 
     def counters(self) -> dict:
-        out = np.zeros(4, np.uint32)
+        out = np.zeros(6, np.uint32)
         self._check(lib().topo_get_counters(self._h, _p(out)))
-        return {"blocks_rastered": int(out[0]), "big_items": int(out[1]), "status": int(out[2]), "rare_items": int(out[3])}
+        return {"blocks_rastered": int(out[0]) + int(out[5]), "big_items": int(out[1]), "status": int(out[2]), "rare_items": int(out[3]),
+                "near_blocks": int(out[0]), "far_tested": int(out[4]), "far_survived": int(out[5])}
+
+    def set_occlusion_split(self, metres: float):
+        self._check(lib().topo_set_occlusion_split(self._h, metres))
 
     def read_normals(self, lat_deg, lon_deg) -> np.ndarray:
         w, h = self.tile_size

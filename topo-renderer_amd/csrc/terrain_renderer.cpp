@@ -67,7 +67,7 @@ TerrainRenderer::~TerrainRenderer() {
         (void)hipFree(kv.second.d_normals);
         (void)hipFree(kv.second.d_minmax);
     }
-    void* bufs[] = {d_tiles_, d_views_, d_vis_, d_work_, d_big_, d_rare_, d_counters_, d_out_rgba_, d_out_depth_,
+    void* bufs[] = {d_tiles_, d_views_, d_vis_, d_work_, d_work2_, d_far_, d_big_, d_rare_, d_counters_, d_out_rgba_, d_out_depth_,
                     d_edge_jobs_, d_corner_jobs_, d_peaks_, d_proj_};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
@@ -233,10 +233,10 @@ int TerrainRenderer::recompute_normals() {
     for (Tile* t : order) collect_jobs(*t, rk, edges, corners);
     if (int rc = ensure(&d_edge_jobs_, &cap_edge_jobs_, (edges.size() + 1) * sizeof(EdgeJob))) return rc;
     if (int rc = ensure(&d_corner_jobs_, &cap_corner_jobs_, (corners.size() + 1) * sizeof(CornerJob))) return rc;
-    TOPO_HIP_TRY(hipEventRecord(ev_[7], stream_));
+    TOPO_HIP_TRY(hipEventRecord(ev_[9], stream_));
     launch_normals_interior((const TileDev*)d_tiles_, 0, (uint32_t)order.size(), tile_w_, tile_h_, lds_rows_, stream_);
     if (int rc = run_seam_jobs(edges, corners)) return rc;
-    TOPO_HIP_TRY(hipEventRecord(ev_[8], stream_));
+    TOPO_HIP_TRY(hipEventRecord(ev_[10], stream_));
     TOPO_HIP_TRY(hipStreamSynchronize(stream_));   // the job lists are locals
     load_timed_ = true;
     TOPO_HIP_TRY(hipGetLastError());
@@ -284,6 +284,8 @@ int TerrainRenderer::render_views_device(uint32_t n, const topo_uniforms* views,
     if (int rc = ensure(&d_vis_, &cap_vis_, pixels * 8)) return rc;
     if (int rc = ensure(&d_views_, &cap_views_, sizeof(ViewDev) * kMaxViewsPerSlot * kViewSlots)) return rc;
     if (int rc = ensure(&d_work_, &cap_work_, (work_cap ? work_cap : 1) * sizeof(WorkItem))) return rc;
+    if (int rc = ensure(&d_work2_, &cap_work2_, (work_cap ? work_cap : 1) * sizeof(WorkItem))) return rc;
+    if (int rc = ensure(&d_far_, &cap_far_, (work_cap ? work_cap : 1) * sizeof(FarItem))) return rc;
     if (int rc = ensure(&d_big_, &cap_big_, big_cap * sizeof(BigItem))) return rc;
     if (int rc = ensure(&d_rare_, &cap_rare_, rare_cap * sizeof(RareItem))) return rc;
     if (!d_counters_) {
@@ -322,6 +324,9 @@ int TerrainRenderer::render_views_device(uint32_t n, const topo_uniforms* views,
     p.counters = (uint32_t*)d_counters_;
     p.big = (BigItem*)d_big_;
     p.rare = (RareItem*)d_rare_;
+    p.far = (FarItem*)d_far_;
+    p.work2 = (WorkItem*)d_work2_;
+    p.split_m = occlusion_split_m_;
     p.rare_cap = (uint32_t)rare_cap;
     p.work_cap = (uint32_t)work_cap;
     p.big_cap = (uint32_t)big_cap;
@@ -342,19 +347,33 @@ int TerrainRenderer::render_views_device(uint32_t n, const topo_uniforms* views,
     }
     last_blocks_tested_ = (uint32_t)work_cap;
 
+    // clear -> cull -> [near blocks: raster, rare, big] -> occlusion test of the far blocks -> [survivors: raster,
+    // rare, big] -> resolve.  Event slots: 0 clear, 1 cull, 2 raster(near), 3 rare+big(near), 4 occlusion,
+    // 5 raster(far), 6 rare+big(far), 7 resolve.
     TOPO_HIP_TRY(hipEventRecord(ev_[0], stream_));
     launch_clear(p, stream_);
     TOPO_HIP_TRY(hipEventRecord(ev_[1], stream_));
     launch_cull(p, stream_);
     TOPO_HIP_TRY(hipEventRecord(ev_[2], stream_));
-    launch_raster(p, stream_);
+    launch_raster(p, 0, stream_);
     TOPO_HIP_TRY(hipEventRecord(ev_[3], stream_));
     launch_raster_rare(p, stream_);
-    TOPO_HIP_TRY(hipEventRecord(ev_[4], stream_));
     launch_raster_big(p, stream_);
+    TOPO_HIP_TRY(hipEventRecord(ev_[4], stream_));
+    if (p.split_m > 0.0f) {
+        launch_phase_mark(p, stream_);
+        launch_occlusion(p, stream_);
+    }
     TOPO_HIP_TRY(hipEventRecord(ev_[5], stream_));
-    launch_resolve(p, out, stream_);
+    if (p.split_m > 0.0f) launch_raster(p, 1, stream_);
     TOPO_HIP_TRY(hipEventRecord(ev_[6], stream_));
+    if (p.split_m > 0.0f) {
+        launch_raster_rare(p, stream_);
+        launch_raster_big(p, stream_);
+    }
+    TOPO_HIP_TRY(hipEventRecord(ev_[7], stream_));
+    launch_resolve(p, out, stream_);
+    TOPO_HIP_TRY(hipEventRecord(ev_[8], stream_));
     frame_timed_ = true;
     TOPO_HIP_TRY(hipGetLastError());
     return TOPO_OK;
@@ -440,6 +459,12 @@ int TerrainRenderer::set_normals_lds_rows(int rows) {
     return TOPO_OK;
 }
 
+int TerrainRenderer::set_occlusion_split(float metres) {
+    if (!(metres >= 0.0f)) return fail(TOPO_ERR_INVALID, "split must be >= 0");
+    occlusion_split_m_ = metres;
+    return TOPO_OK;
+}
+
 int TerrainRenderer::set_queue_caps(uint32_t big_cap, uint32_t rare_cap) {
     big_cap_cfg_ = big_cap;
     rare_cap_cfg_ = rare_cap;
@@ -454,25 +479,32 @@ int TerrainRenderer::get_timings(float out[TOPO_TIMING_SLOTS]) {
     for (int i = 0; i < TOPO_TIMING_SLOTS; ++i) out[i] = 0.0f;
     if (int rc = bind_device()) return rc;
     if (frame_timed_) {
-        TOPO_HIP_TRY(hipEventSynchronize(ev_[6]));
-        for (int i = 0; i < 6; ++i) TOPO_HIP_TRY(hipEventElapsedTime(&out[i], ev_[i], ev_[i + 1]));
-        TOPO_HIP_TRY(hipEventElapsedTime(&out[6], ev_[0], ev_[6]));
+        TOPO_HIP_TRY(hipEventSynchronize(ev_[8]));
+        float d[8];
+        for (int i = 0; i < 8; ++i) TOPO_HIP_TRY(hipEventElapsedTime(&d[i], ev_[i], ev_[i + 1]));
+        out[0] = d[0];                // clear
+        out[1] = d[1];                // cull
+        out[2] = d[2] + d[5];         // raster: near blocks + far survivors
+        out[3] = d[4];                // occlusion test
+        out[4] = d[3] + d[6];         // rare + big (both phases)
+        out[5] = d[7];                // resolve
+        TOPO_HIP_TRY(hipEventElapsedTime(&out[6], ev_[0], ev_[8]));
     }
     if (load_timed_) {
-        TOPO_HIP_TRY(hipEventSynchronize(ev_[8]));
-        TOPO_HIP_TRY(hipEventElapsedTime(&out[7], ev_[7], ev_[8]));
+        TOPO_HIP_TRY(hipEventSynchronize(ev_[10]));
+        TOPO_HIP_TRY(hipEventElapsedTime(&out[7], ev_[9], ev_[10]));
     }
     return TOPO_OK;
 }
 
 int TerrainRenderer::get_counters(uint32_t out[4]) {
-    out[0] = out[1] = out[2] = out[3] = 0;
+    for (int i = 0; i < 6; ++i) out[i] = 0;
     if (!d_counters_) return TOPO_OK;
     if (int rc = bind_device()) return rc;
     TOPO_HIP_TRY(hipStreamSynchronize(stream_));
-    uint32_t c[4];
+    uint32_t c[8];
     TOPO_HIP_TRY(hipMemcpy(c, d_counters_, sizeof c, hipMemcpyDeviceToHost));
-    out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+    out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3]; out[4] = c[4]; out[5] = c[5];
     return TOPO_OK;
 }
 

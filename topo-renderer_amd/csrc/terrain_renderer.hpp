@@ -52,7 +52,8 @@ class TerrainRenderer {
     int set_normals_lds_rows(int rows);
     int set_queue_caps(uint32_t big_cap, uint32_t rare_cap);
     int get_timings(float out[TOPO_TIMING_SLOTS]);
-    int get_counters(uint32_t out[4]);
+    int get_counters(uint32_t out[6]);
+    int set_occlusion_split(float metres);
     int read_normals(int32_t lat, int32_t lon, uint8_t* out);
     int probe_sincos(const float* x, float* s, float* c, size_t n);
     int visible_peaks(uint32_t n, const float* peaks, uint8_t* visible, uint32_t* xy);
@@ -85,9 +86,10 @@ class TerrainRenderer {
     bool table_dirty_ = true;
     int lds_rows_ = 16;
     uint32_t big_cap_cfg_ = 0, rare_cap_cfg_ = 0;
+    float occlusion_split_m_ = 60000.0f;
 
     hipStream_t own_stream_ = nullptr, stream_ = nullptr;
-    static constexpr int kNumEvents = 9;
+    static constexpr int kNumEvents = 11;
     hipEvent_t ev_[kNumEvents] = {};
     bool frame_timed_ = false, load_timed_ = false;
 
@@ -96,6 +98,8 @@ class TerrainRenderer {
     void* d_views_ = nullptr;    size_t cap_views_ = 0;
     void* d_vis_ = nullptr;      size_t cap_vis_ = 0;
     void* d_work_ = nullptr;     size_t cap_work_ = 0;
+    void* d_work2_ = nullptr;    size_t cap_work2_ = 0;
+    void* d_far_ = nullptr;      size_t cap_far_ = 0;
     void* d_big_ = nullptr;      size_t cap_big_ = 0;
     void* d_rare_ = nullptr;     size_t cap_rare_ = 0;
     void* d_edge_jobs_ = nullptr;   size_t cap_edge_jobs_ = 0;

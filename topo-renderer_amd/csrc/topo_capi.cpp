@@ -126,7 +126,12 @@ int topo_get_timings(topo_ctx* ctx, float out_ms[TOPO_TIMING_SLOTS]) {
     TOPO_CALL(ctx->r->get_timings(out_ms));
 }
 
-int topo_get_counters(topo_ctx* ctx, uint32_t out[4]) {
+int topo_set_occlusion_split(topo_ctx* ctx, float metres) {
+    TOPO_GUARD(ctx);
+    return ctx->r->set_occlusion_split(metres);
+}
+
+int topo_get_counters(topo_ctx* ctx, uint32_t out[6]) {
     TOPO_GUARD(ctx);
     TOPO_CALL(ctx->r->get_counters(out));
 }

@@ -18,6 +18,13 @@ struct WorkItem {          // one (view, tile, block) that survived the frustum 
     uint32_t block;        // by * bx_count + bx
 };
 
+struct FarItem {           // a frustum-surviving block beyond the occlusion split, with its conservative screen footprint
+    uint32_t view_rank;
+    uint32_t block;
+    uint16_t x0, x1, y0, y1;   // inclusive pixel box of everything the block can draw (already clamped to the target)
+    uint32_t zmin_bits;        // f32 bits of a lower bound of every depth the block can produce
+};
+
 struct BigItem {           // a triangle too large for the in-lane loop, restricted to one 64x64 px region
     uint32_t view;
     uint32_t id;           // draw << 1 | fan   (kNoTri = empty slot)
@@ -36,10 +43,14 @@ struct FrameParams {
     const ViewDev* views;      // n_views
     uint64_t* vis;             // n_views * W * H visibility keys: depth bits << 32 | id
     WorkItem* work;
-    uint32_t* counters;        // [0] work count, [1] big count, [2] status bits, [3] rare count
+    uint32_t* counters;        // [0] near work count, [1] big count, [2] status bits, [3] rare count, [4] far candidates,
+                               // [5] far survivors, [6] big start, [7] rare start (of the current phase)
     BigItem* big;
     RareItem* rare;
+    FarItem* far;              // far candidates (k_cull -> k_occlusion)
+    WorkItem* work2;           // far survivors (k_occlusion -> second k_raster)
     uint32_t work_cap, big_cap, rare_cap;
+    float split_m;             // view depth (m) beyond which a block is an occlusion-test candidate; 0 = feature off
     uint32_t n_views, n_tiles;
     int32_t W, H;
     uint32_t tile_w, tile_h;
@@ -81,7 +92,9 @@ void launch_normals_corners(const TileDev* tiles, const CornerJob* jobs, uint32_
 // frame phase (render)
 void launch_clear(const FrameParams& p, hipStream_t s);
 void launch_cull(const FrameParams& p, hipStream_t s);
-void launch_raster(const FrameParams& p, hipStream_t s);
+void launch_raster(const FrameParams& p, int phase, hipStream_t s);   // phase 0: near list, 1: far survivors
+void launch_phase_mark(const FrameParams& p, hipStream_t s);
+void launch_occlusion(const FrameParams& p, hipStream_t s);
 void launch_raster_rare(const FrameParams& p, hipStream_t s);
 void launch_raster_big(const FrameParams& p, hipStream_t s);
 void launch_resolve(const FrameParams& p, const OutputParams& o, hipStream_t s);

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(64) void k_normals_corner(const TileDev* __restrict
 // ======================================================================================================
 
 __global__ __launch_bounds__(256) void k_clear(uint64_t* __restrict__ vis, size_t n, uint32_t* __restrict__ counters) {
-    if (blockIdx.x == 0 && threadIdx.x < 4 && threadIdx.x != 2) counters[threadIdx.x] = 0;   // work/big/rare counts (status is sticky)
+    if (blockIdx.x == 0 && threadIdx.x < 8 && threadIdx.x != 2) counters[threadIdx.x] = 0;   // all queue counters (status is sticky)
     const size_t stride = (size_t)gridDim.x * blockDim.x * 2;
     for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 2; i < n; i += stride) {
         if (i + 1 < n) {
@@ -168,15 +168,17 @@ __global__ __launch_bounds__(256) void k_clear(uint64_t* __restrict__ vis, size_
 // Conservative frustum test of one raster block against one view, in f64.  A block is kept unless its
 // bounding sphere (inflated by 64 m for the f32 noise of the real vertex path) lies wholly outside one of
 // the six clip planes of camera_proj.  Culling is result-neutral: culled blocks cannot produce fragments.
-__device__ void world_f64(const TileDev& t, double vx, double vy, double height, double out[3]) {
-    const double lon = ((vx - (double)t.raster_x) * (double)t.scale_x + (double)t.model_x) * 0.017453292519943295;
-    const double lat = ((vy - (double)t.raster_y) * -(double)t.scale_y + (double)t.model_y) * 0.017453292519943295;
-    const double R = (double)kR0 + height;
-    out[0] = R * cos(lat) * cos(lon);
-    out[1] = R * cos(lat) * sin(lon);
-    out[2] = R * sin(lat);
-}
+struct SinCos64 { double s, c; };
+__device__ __forceinline__ SinCos64 sincos64(double a) { SinCos64 r; r.s = sin(a); r.c = cos(a); return r; }
 
+// One lane per (view, tile, block).  f64 throughout; everything here is a conservative, result-neutral filter:
+//  * frustum: the block's bounding sphere (inflated by 72 m for the f32 noise of the real vertex path) against the
+//    six clip planes of camera_proj -- culled blocks cannot produce fragments;
+//  * near/far split: blocks whose nearest possible view depth exceeds P.split_m become occlusion-test candidates
+//    (FarItem) instead of work items; for them the lane also projects the eight corners of the block's bounding
+//    slab -- the lat/lon rectangle of its vertices x [hmin - 1 m, hmax + 2 m], which contains every triangle of the
+//    block up to < 1 m of chord sagitta -- and records the pixel box (+-2 px) and a lower bound of the depths
+//    (z_ndc at the smallest corner w, minus 8/w: the f32 clip-space cancellation noise is ~1 clip unit).
 __global__ __launch_bounds__(256) void k_cull(FrameParams P) {
     const uint32_t blocks_per_tile = P.bx_count * P.by_count;
     const size_t total = (size_t)P.n_views * P.n_tiles * blocks_per_tile;
@@ -193,13 +195,23 @@ __global__ __launch_bounds__(256) void k_cull(FrameParams P) {
     if (y1 > (double)(P.tile_h - 1)) y1 = (double)(P.tile_h - 1);
     const double hmin = (double)t.block_minmax[2 * blk], hmax = (double)t.block_minmax[2 * blk + 1];
     const double hmid = 0.5 * (hmin + hmax);
-    double c[3], q[3];
-    world_f64(t, 0.5 * (x0 + x1), 0.5 * (y0 + y1), hmid, c);
-    double r2 = 0.0;
-    const double cxs[4] = {x0, x1, x0, x1}, cys[4] = {y0, y0, y1, y1};
+    const double D2R = 0.017453292519943295;
+    auto lon_of = [&](double vx) { return ((vx - (double)t.raster_x) * (double)t.scale_x + (double)t.model_x) * D2R; };
+    auto lat_of = [&](double vy) { return ((vy - (double)t.raster_y) * -(double)t.scale_y + (double)t.model_y) * D2R; };
+    const SinCos64 lo[2] = {sincos64(lon_of(x0)), sincos64(lon_of(x1))}, la[2] = {sincos64(lat_of(y0)), sincos64(lat_of(y1))};
+    const SinCos64 loc = sincos64(lon_of(0.5 * (x0 + x1))), lac = sincos64(lat_of(0.5 * (y0 + y1)));
+    // unit directions of the four corners and the centre
+    double u[4][3];
     for (int k = 0; k < 4; ++k) {
-        world_f64(t, cxs[k], cys[k], hmid, q);
-        const double d2 = (q[0] - c[0]) * (q[0] - c[0]) + (q[1] - c[1]) * (q[1] - c[1]) + (q[2] - c[2]) * (q[2] - c[2]);
+        const SinCos64 &o = lo[k & 1], &a = la[k >> 1];
+        u[k][0] = a.c * o.c; u[k][1] = a.c * o.s; u[k][2] = a.s;
+    }
+    const double Rm = (double)kR0 + hmid;
+    const double c[3] = {Rm * lac.c * loc.c, Rm * lac.c * loc.s, Rm * lac.s};
+    double r2 = 0.0;
+    for (int k = 0; k < 4; ++k) {
+        const double dx = Rm * u[k][0] - c[0], dy = Rm * u[k][1] - c[1], dz = Rm * u[k][2] - c[2];
+        const double d2 = dx * dx + dy * dy + dz * dz;
         r2 = d2 > r2 ? d2 : r2;
     }
     // corners bound the patch up to its sagitta (< 1 m for a 6 km block); + half the height range + margin
@@ -222,10 +234,83 @@ __global__ __launch_bounds__(256) void k_cull(FrameParams P) {
         const double nrm = sqrt(a * a + b * b + cc * cc);
         if (dist < -radius * nrm) keep = false;
     }
-    if (!(hmin <= hmax)) keep = true;       // NaN heights: let the raster path deal with it
-    if (keep) {
-        const uint32_t slot = atomicAdd(&P.counters[0], 1u);
-        if (slot < P.work_cap) P.work[slot] = WorkItem{(view << 16) | rank, blk};
+    const bool sane = hmin <= hmax;         // NaN heights: no filtering at all, the raster path deals with it
+    if (!sane) keep = true;
+    if (!keep) return;
+    // view depth of the nearest point the block can contain
+    const double wn = sqrt((double)m[3] * m[3] + (double)m[7] * m[7] + (double)m[11] * m[11]);
+    const double w_near = ((double)m[3] * c[0] + (double)m[7] * c[1] + (double)m[11] * c[2] + (double)m[15]) - radius * wn;
+    if (sane && P.split_m > 0.0f && w_near > (double)P.split_m) {
+        double bxlo = 1e30, bxhi = -1e30, bylo = 1e30, byhi = -1e30, wmin = 1e30, zclip_at_wmin = 0.0;
+        const double hs[2] = {hmin - 1.0, hmax + 2.0};
+        for (int k = 0; k < 8; ++k) {
+            const double R = (double)kR0 + hs[k >> 2];
+            const double px = R * u[k & 3][0], py = R * u[k & 3][1], pz = R * u[k & 3][2];
+            const double cx = (double)m[0] * px + (double)m[4] * py + (double)m[8] * pz + (double)m[12];
+            const double cy = (double)m[1] * px + (double)m[5] * py + (double)m[9] * pz + (double)m[13];
+            const double cz = (double)m[2] * px + (double)m[6] * py + (double)m[10] * pz + (double)m[14];
+            const double cw = (double)m[3] * px + (double)m[7] * py + (double)m[11] * pz + (double)m[15];
+            const double sx = (cx / cw * 0.5 + 0.5) * (double)P.W, sy = (0.5 - cy / cw * 0.5) * (double)P.H;
+            bxlo = sx < bxlo ? sx : bxlo; bxhi = sx > bxhi ? sx : bxhi;
+            bylo = sy < bylo ? sy : bylo; byhi = sy > byhi ? sy : byhi;
+            if (cw < wmin) { wmin = cw; zclip_at_wmin = cz; }
+        }
+        // z_ndc = a + b / w (b < 0) is a function of w alone and w is linear in position, so over the slab's convex
+        // hull its minimum sits at the corner with the smallest w.  The real pipeline computes z_clip and w as f32
+        // fma chains over ~6.4e6-sized terms: each carries up to ~1 (metre-sized clip units) of cancellation noise,
+        // i.e. z_ndc is only good to ~2 / w.  Shave 8 / w.
+        double zmin = zclip_at_wmin / wmin - 8.0 / wmin;
+        if (wmin > 1000.0 && zmin > 0.0 && zmin < 1.0) {
+            const int32_t ix0 = max((int32_t)floor(bxlo) - 2, 0), ix1 = min((int32_t)ceil(bxhi) + 2, P.W - 1);
+            const int32_t iy0 = max((int32_t)floor(bylo) - 2, 0), iy1 = min((int32_t)ceil(byhi) + 2, P.H - 1);
+            if (ix0 > ix1 || iy0 > iy1) return;     // wholly outside the target even with the margin
+            float zf = (float)zmin;
+            if ((double)zf > zmin) zf = bits_f(f_bits(zf) - 1u);      // round down
+            const uint32_t slot = atomicAdd(&P.counters[4], 1u);
+            if (slot < P.work_cap) {
+                FarItem fi;
+                fi.view_rank = (view << 16) | rank; fi.block = blk;
+                fi.x0 = (uint16_t)ix0; fi.x1 = (uint16_t)ix1; fi.y0 = (uint16_t)iy0; fi.y1 = (uint16_t)iy1;
+                fi.zmin_bits = f_bits(zf);
+                P.far[slot] = fi;
+            }
+            return;
+        }
+    }
+    const uint32_t slot = atomicAdd(&P.counters[0], 1u);
+    if (slot < P.work_cap) P.work[slot] = WorkItem{(view << 16) | rank, blk};
+}
+
+// One wave per far candidate: the block is dropped iff EVERY pixel of its footprint already holds a depth below
+// the block's lower bound -- then none of its fragments could pass `Less`.  Pixels in the gaps between tiles, or
+// anywhere nothing nearer has been drawn, keep the block alive, so the filter is exact by construction.
+__global__ __launch_bounds__(256) void k_occlusion(FrameParams P) {
+    uint32_t count = P.counters[4];
+    if (count > P.work_cap) count = P.work_cap;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave_global = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wave_count = gridDim.x * 4;
+    for (uint32_t item = wave_global; item < count; item += wave_count) {
+        const FarItem fi = P.far[item];
+        const uint64_t* vis = P.vis + (size_t)(fi.view_rank >> 16) * P.W * P.H;
+        bool visible = false;
+        for (uint32_t y = fi.y0; y <= fi.y1 && !visible; ++y)
+            for (uint32_t x = fi.x0; x <= fi.x1; x += 64) {
+                const uint32_t px = x + lane;
+                const bool open = px <= fi.x1 && (uint32_t)(vis[(size_t)y * P.W + px] >> 32) >= fi.zmin_bits;
+                if (__any(open)) { visible = true; break; }
+            }
+        if (visible && lane == 0) {
+            const uint32_t slot = atomicAdd(&P.counters[5], 1u);
+            if (slot < P.work_cap) P.work2[slot] = WorkItem{fi.view_rank, fi.block};
+        }
+    }
+}
+
+// Between the two raster phases: the rare/big queues keep growing, the second phase starts where the first ended.
+__global__ void k_phase_mark(uint32_t* counters) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        counters[6] = counters[1];
+        counters[7] = counters[3];
     }
 }
 
@@ -468,10 +553,11 @@ __device__ __forceinline__ SVert shfl_down1(const SVert& v) {
 #ifndef TOPO_RASTER_WAVES
 #define TOPO_RASTER_WAVES 5
 #endif
-__global__ __launch_bounds__(256, TOPO_RASTER_WAVES) void k_raster(FrameParams P) {
+__global__ __launch_bounds__(256, TOPO_RASTER_WAVES) void k_raster(FrameParams P, int phase) {
     __shared__ FragList s_fl[4];
     __shared__ TriList s_tl[4];
-    uint32_t count = P.counters[0];
+    const WorkItem* __restrict__ work = phase == 0 ? P.work : P.work2;
+    uint32_t count = P.counters[phase == 0 ? 0 : 5];
     if (count > P.work_cap) count = P.work_cap;
     // the wave index is wave-uniform: say so (readfirstlane), or the compiler treats everything derived from the
     // work item -- the view matrix, the tile descriptor -- as per-lane data and re-loads it with vector loads.
@@ -482,7 +568,7 @@ __global__ __launch_bounds__(256, TOPO_RASTER_WAVES) void k_raster(FrameParams P
     uint32_t ntri = 0;           // triangles waiting in tl (wave-uniform)
     const uint32_t wave_global = blockIdx.x * 4 + wave, wave_count = gridDim.x * 4;
     for (uint32_t item = wave_global; item < count; item += wave_count) {
-        const WorkItem wi = P.work[item];
+        const WorkItem wi = work[item];
         const uint32_t view_idx = wi.view_rank >> 16, rank = wi.view_rank & 0xFFFFu;
         const TileDev& t = P.tiles[rank];
         const ViewDev& view = P.views[view_idx];
@@ -582,7 +668,7 @@ __global__ __launch_bounds__(256, TOPO_RASTER_WAVES) void k_raster(FrameParams P
 __global__ __launch_bounds__(256) void k_raster_rare(FrameParams P) {
     uint32_t count = P.counters[3];
     if (count > P.rare_cap) count = P.rare_cap;
-    for (uint32_t item = blockIdx.x * blockDim.x + threadIdx.x; item < count; item += gridDim.x * blockDim.x) {
+    for (uint32_t item = P.counters[7] + blockIdx.x * blockDim.x + threadIdx.x; item < count; item += gridDim.x * blockDim.x) {
         const RareItem ri = P.rare[item];
         const uint32_t rank = ri.draw / P.tris_per_tile, tri = ri.draw - rank * P.tris_per_tile;
         uint64_t* vis = P.vis + (size_t)ri.view * P.W * P.H;
@@ -621,7 +707,7 @@ __global__ __launch_bounds__(256) void k_raster_big(FrameParams P) {
     const uint32_t lane = threadIdx.x & 63;
     const int32_t lx = (int32_t)(lane & 7), ly = (int32_t)(lane >> 3);
     const uint32_t wave_global = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wave_count = gridDim.x * 4;
-    for (uint32_t item = wave_global; item < count; item += wave_count) {
+    for (uint32_t item = P.counters[6] + wave_global; item < count; item += wave_count) {
         const BigItem bi = P.big[item];      // wave-uniform: scalar loads, scalar setup
         if (bi.id == kNoTri) continue;
         uint64_t* vis = P.vis + (size_t)bi.view * P.W * P.H;
@@ -842,10 +928,18 @@ static unsigned resident_grid(K kernel, unsigned fallback) {
     return (unsigned)(cus * per_cu);
 }
 
-void launch_raster(const FrameParams& p, hipStream_t s) {
+void launch_raster(const FrameParams& p, int phase, hipStream_t s) {
     if (p.n_tiles == 0) return;
     static const unsigned grid = resident_grid(k_raster, 256 * 5);
-    hipLaunchKernelGGL(k_raster, dim3(grid), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(k_raster, dim3(grid), dim3(256), 0, s, p, phase);
+}
+
+void launch_phase_mark(const FrameParams& p, hipStream_t s) { hipLaunchKernelGGL(k_phase_mark, dim3(1), dim3(64), 0, s, p.counters); }
+
+void launch_occlusion(const FrameParams& p, hipStream_t s) {
+    if (p.n_tiles == 0) return;
+    static const unsigned grid = resident_grid(k_occlusion, 256 * 8);
+    hipLaunchKernelGGL(k_occlusion, dim3(grid), dim3(256), 0, s, p);
 }
 
 void launch_raster_rare(const FrameParams& p, hipStream_t s) {
