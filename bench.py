@@ -149,26 +149,41 @@ def main():
     mpix = PW * PH / 1e6
     value = mpix / (ms_per_step / 1e3)
 
-    # ---- roofline of the dominant kernel (k_raster): algorithmic bytes = the DEM heights it must read once,
-    # 4 B per texel of every tile this rank rasterises (SURVEY.md 8d "DEM read"); at N ranks each launch covers
-    # the tiles seen by its sectors, priced here as the full mosaic / N.
-    dem_bytes = 4.0 * n_tiles * TILE * TILE / world
-    raster_s = kernel_ms["raster"] / 1e3
-    achieved = dem_bytes / raster_s / 1e9 if raster_s > 0 else 0.0
-    roofline = {"bound": "hbm", "kernel": "k_raster", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+    # ---- roofline of the dominant kernel = the frame kernel with the largest mean duration (HIP events on the launch
+    # stream).  Algorithmic bytes per launch:
+    #   k_resolve : 8 B visibility key read + 4 B RGBA8 + 4 B depth written per pixel of this rank's sectors;
+    #   k_raster  : 4 B per DEM texel of the mosaic share this rank is responsible for ("DEM read" = 4*T*W*H / N) --
+    #               since the occlusion filter most of those texels are ruled out from the 8-byte-per-block min/max
+    #               table instead of being read, so this prices the stage, not the bytes the kernel touches.
+    my_pixels = per * SW * PH
+    alg = {"resolve": ("k_resolve", 16.0 * my_pixels),
+           "raster": ("k_raster", 4.0 * n_tiles * TILE * TILE / world),
+           "raster_big": ("k_raster_rare+k_raster_big", 8.0 * my_pixels)}
+    dom = max(alg, key=lambda k: kernel_ms[k])
+    dom_name, dom_bytes = alg[dom]
+    dom_s = kernel_ms[dom] / 1e3
+    achieved = dom_bytes / dom_s / 1e9 if dom_s > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
-                "algorithmic_bytes_per_launch": dem_bytes, "avg_launch_ms": round(kernel_ms["raster"], 4)}
-    # HBM bytes per k_raster launch from the PMC counters cannot be collected from inside this process; they are
-    # measured in separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this same command
+                "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": round(kernel_ms[dom], 4)}
+    # HBM bytes per launch from the PMC counters cannot be collected from inside this process; they are measured in
+    # separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this same command
     # (tools/collect_hbm_pmc.sh) and read back from profiles/hbm_traffic.json when it matches the workload.
     try:
         with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
             tr = json.load(f)
-        if tr.get("workload") == args.workload and tr.get("n_gpus") == world and tr.get("kernel") == "k_raster":
-            roofline["traffic"] = tr["bytes_per_launch"]
+        ent = tr.get("kernels", {}).get(dom_name.split("+")[-1])
+        if tr.get("workload") == args.workload and tr.get("n_gpus") == world and ent:
+            roofline["traffic"] = ent["bytes_per_launch"]
             roofline["traffic_source"] = tr.get("source")
     except (OSError, ValueError, KeyError):
         pass
+    dem_bytes = 4.0 * n_tiles * TILE * TILE / world
+    stage_ms = kernel_ms["cull"] + kernel_ms["raster"] + kernel_ms["occlusion"] + kernel_ms["raster_big"]
+    per_kernel = {name: {"ms": round(kernel_ms[k], 4), "algorithmic_GBps": round(b / (kernel_ms[k] / 1e3) / 1e9, 1) if kernel_ms[k] > 0 else None}
+                  for k, (name, b) in alg.items()}
+    per_kernel["dem_to_visibility_stage"] = {"ms": round(stage_ms, 4), "what": "cull + raster + occlusion + rare + big against the DEM read (4*T*W*H/N)",
+                                             "algorithmic_GBps": round(dem_bytes / (stage_ms / 1e3) / 1e9, 1) if stage_ms > 0 else None}
 
     out = {
         "metric": "panorama Mpix/s",
@@ -187,6 +202,7 @@ def main():
                                f"{PW}x{PH} panorama = 8 sectors of {SW}x{PH}, view_mode {args.view_mode}",
                    "sharding": f"azimuth sectors, {per} per GPU, DEM replicated" + (", RCCL all-gather of RGBA" if world > 1 else "")},
         "roofline": roofline,
+        "per_kernel": per_kernel,
         "kernel_ms": {k: round(v, 4) for k, v in kernel_ms.items()},
         "load_ms": round(load_ms, 4),
         "load_GBps": round(8.0 * n_tiles * TILE * TILE / (load_ms / 1e3) / 1e9, 1) if load_ms > 0 else None,

@@ -25,12 +25,16 @@ for f in glob.glob(os.path.join(root, "*", "*", "*_counter_collection.csv")):
 med = {k: {c: sorted(v)[len(v) // 2] for c, v in d.items()} for k, d in agg.items()}
 tile_bytes = 1200 * 1200 * 4
 cal = tile_bytes / med["k_block_minmax"]["FETCH_SIZE"] if "k_block_minmax" in med else 1.0
-out = {"workload": workload, "n_gpus": 1, "kernel": "k_raster",
-       "fetch_size_raw": med["k_raster"]["FETCH_SIZE"], "write_size": med["k_raster"]["WRITE_SIZE"],
-       "fetch_calibration": round(cal, 4),
-       "bytes_per_launch": round(med["k_raster"]["FETCH_SIZE"] * cal + med["k_raster"]["WRITE_SIZE"]),
-       "per_kernel_raw": {k: {c: round(v) for c, v in d.items()} for k, d in med.items()},
-       "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), median per launch; FETCH_SIZE corrected by "
-                 "the k_block_minmax calibration (same 61-lane dword row reads, known bytes)"}
+kernels = {}
+for k, d in med.items():
+    f, w = d.get("FETCH_SIZE", 0.0), d.get("WRITE_SIZE", 0.0)
+    # only k_raster's reads (61-lane dword rows) share k_block_minmax's pattern; the other kernels keep the raw count
+    fc = f * cal if k == "k_raster" else f
+    kernels[k] = {"fetch_size_raw": round(f), "write_size": round(w), "bytes_per_launch": round(fc + w),
+                  "fetch_calibrated": k == "k_raster"}
+out = {"workload": workload, "n_gpus": 1, "fetch_calibration_dword_rows": round(cal, 4), "kernels": kernels,
+       "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), median per launch; k_raster's FETCH_SIZE "
+                 "corrected by the k_block_minmax calibration (same 61-lane dword row reads, known bytes); other kernels raw "
+                 "(FETCH_SIZE is uncalibrated for their access widths on gfx950)"}
 print(json.dumps(out, indent=1))
 json.dump(out, open(os.path.join(os.path.dirname(root), "hbm_traffic.json"), "w"), indent=1)
