@@ -280,10 +280,11 @@ int TerrainRenderer::render_views_device(uint32_t n, const topo_uniforms* views,
     const size_t pixels = (size_t)n * w * h;
     const size_t work_cap = (size_t)n * n_tiles * bxc * byc;
     const size_t big_cap = big_cap_cfg_ ? big_cap_cfg_ : (1u << 22), rare_cap = rare_cap_cfg_ ? rare_cap_cfg_ : (1u << 22);
-    if (work_cap >= (1ull << 32)) return fail(TOPO_ERR_CAPACITY, "too many raster blocks in one submission");
+    if (work_cap >= (1ull << 30)) return fail(TOPO_ERR_CAPACITY, "too many raster blocks in one submission");
     if (int rc = ensure(&d_vis_, &cap_vis_, pixels * 8)) return rc;
     if (int rc = ensure(&d_views_, &cap_views_, sizeof(ViewDev) * kMaxViewsPerSlot * kViewSlots)) return rc;
-    if (int rc = ensure(&d_work_, &cap_work_, (work_cap ? work_cap : 1) * sizeof(WorkItem))) return rc;
+    const size_t near_cap = 4 * work_cap;   // a near block is cut into up to 4 strips
+    if (int rc = ensure(&d_work_, &cap_work_, (near_cap ? near_cap : 1) * sizeof(WorkItem))) return rc;
     if (int rc = ensure(&d_work2_, &cap_work2_, (work_cap ? work_cap : 1) * sizeof(WorkItem))) return rc;
     if (int rc = ensure(&d_far_, &cap_far_, (work_cap ? work_cap : 1) * sizeof(FarItem))) return rc;
     if (int rc = ensure(&d_big_, &cap_big_, big_cap * sizeof(BigItem))) return rc;
@@ -329,6 +330,7 @@ int TerrainRenderer::render_views_device(uint32_t n, const topo_uniforms* views,
     p.split_m = occlusion_split_m_;
     p.rare_cap = (uint32_t)rare_cap;
     p.work_cap = (uint32_t)work_cap;
+    p.near_cap = (uint32_t)near_cap;
     p.big_cap = (uint32_t)big_cap;
     p.n_views = n;
     p.n_tiles = n_tiles;

@@ -49,7 +49,8 @@ struct FrameParams {
     RareItem* rare;
     FarItem* far;              // far candidates (k_cull -> k_occlusion)
     WorkItem* work2;           // far survivors (k_occlusion -> second k_raster)
-    uint32_t work_cap, big_cap, rare_cap;
+    uint32_t work_cap, big_cap, rare_cap;   // work_cap: entries of far / work2 (one per block and view)
+    uint32_t near_cap;                      // entries of work (up to 4 strips per near block)
     float split_m;             // view depth (m) beyond which a block is an occlusion-test candidate; 0 = feature off
     uint32_t n_views, n_tiles;
     int32_t W, H;

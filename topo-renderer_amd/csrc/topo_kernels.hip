@@ -277,8 +277,19 @@ __global__ __launch_bounds__(256) void k_cull(FrameParams P) {
             return;
         }
     }
+    // a near block: with the occlusion filter on these are few and heavy (large triangles), so each is cut into
+    // strips of 4 cell rows to spread them over the resident waves.  block = id | first cell row << 24 | rows << 28
+    if (P.split_m > 0.0f) {
+        const uint32_t cell_rows = min(kBCY, P.tile_h - 1 - by * kBCY);
+        const uint32_t n = (cell_rows + 3) / 4;
+        const uint32_t base = atomicAdd(&P.counters[0], n);
+        for (uint32_t k = 0; k < n; ++k)
+            if (base + k < P.near_cap)
+                P.work[base + k] = WorkItem{(view << 16) | rank, blk | ((4 * k) << 24) | (min(4u, cell_rows - 4 * k) << 28)};
+        return;
+    }
     const uint32_t slot = atomicAdd(&P.counters[0], 1u);
-    if (slot < P.work_cap) P.work[slot] = WorkItem{(view << 16) | rank, blk};
+    if (slot < P.near_cap) P.work[slot] = WorkItem{(view << 16) | rank, blk};     // rows field 0 = the whole block
 }
 
 // One wave per far candidate: the block is dropped iff EVERY pixel of its footprint already holds a depth below
@@ -558,7 +569,8 @@ __global__ __launch_bounds__(256, TOPO_RASTER_WAVES) void k_raster(FrameParams P
     __shared__ TriList s_tl[4];
     const WorkItem* __restrict__ work = phase == 0 ? P.work : P.work2;
     uint32_t count = P.counters[phase == 0 ? 0 : 5];
-    if (count > P.work_cap) count = P.work_cap;
+    const uint32_t cap = phase == 0 ? P.near_cap : P.work_cap;
+    if (count > cap) count = cap;
     // the wave index is wave-uniform: say so (readfirstlane), or the compiler treats everything derived from the
     // work item -- the view matrix, the tile descriptor -- as per-lane data and re-loads it with vector loads.
     // Waves stride statically over the work list (pulling chunks from an atomic cursor measured 17 % slower).
@@ -572,9 +584,10 @@ __global__ __launch_bounds__(256, TOPO_RASTER_WAVES) void k_raster(FrameParams P
         const uint32_t view_idx = wi.view_rank >> 16, rank = wi.view_rank & 0xFFFFu;
         const TileDev& t = P.tiles[rank];
         const ViewDev& view = P.views[view_idx];
-        const uint32_t bx = wi.block % P.bx_count, by = wi.block / P.bx_count;
-        const uint32_t x0 = bx * kBCX, y0 = by * kBCY;
-        const uint32_t nrows = min(kVY, P.tile_h - y0);          // vertex rows in this block
+        const uint32_t blk_id = wi.block & 0xFFFFFFu, strip_first = (wi.block >> 24) & 15u, strip_rows = wi.block >> 28;
+        const uint32_t bx = blk_id % P.bx_count, by = blk_id / P.bx_count;
+        const uint32_t x0 = bx * kBCX, y0 = by * kBCY + strip_first;   // strip_rows == 0: the whole block
+        const uint32_t nrows = min(strip_rows ? strip_rows + 1 : kVY, P.tile_h - y0);   // vertex rows of this item
         const uint32_t ncx = min(kBCX, P.tile_w - 1 - x0);       // cells per row
         const uint32_t vx = x0 + lane;
         const bool vcol = lane < kVX && vx < P.tile_w;
