@@ -29,11 +29,17 @@ def _worker(rank, world, port, expect_path, out_q):
         sc.load(o)
         o.update(sw, sh, views[0], T.post_uniforms(sw, sh))
         rgba, _ = o.render_views([views[k] for k in mine], threads=1)
-        strip = torch.zeros((8, sh, sw, 4), dtype=torch.uint8)
-        strip[mine.start:mine.stop] = torch.from_numpy(rgba)
-        T.panorama.gather_strip(dist, strip, rank, world)
-        expect = torch.from_numpy(np.load(expect_path))
-        out_q.put((rank, bool(torch.equal(strip, expect)), list(mine)))
+        strip = torch.zeros(T.panorama.strip_shape(world, sh, sw), dtype=torch.uint8)
+        works = []
+        for c in range(len(mine)):                 # one slot at a time, as bench.py pipelines it
+            strip[c, rank] = torch.from_numpy(rgba[c])
+            works.append(T.panorama.gather_slot(dist, strip, c, rank, world, async_op=True))
+        for w in works:
+            w.wait()
+        expect = torch.from_numpy(np.load(expect_path))          # [8, H, SW, 4] in sector order
+        ok = all(bool(torch.equal(T.panorama.sector(strip, k), expect[k])) for k in range(8))
+        ok = ok and bool(torch.equal(T.panorama.to_row_major(strip), expect.permute(1, 0, 2, 3).reshape(sh, 8 * sw, 4)))
+        out_q.put((rank, ok, list(mine)))
     finally:
         dist.destroy_process_group()
 
@@ -73,9 +79,15 @@ def test_sector_range_and_row_major(topo):
     assert list(P.sector_range(0, 1)) == list(range(8))
     with pytest.raises(ValueError):
         P.sector_range(0, 3)
-    strip = np.arange(8 * 2 * 3 * 4, dtype=np.int32).reshape(8, 2, 3, 4)
-    rm = P.to_row_major(strip)
-    assert rm.shape == (2, 24, 4)
-    for k in range(8):
-        assert np.array_equal(rm[:, 3 * k:3 * k + 3], strip[k])
-    assert torch.equal(P.to_row_major(torch.from_numpy(strip)), torch.from_numpy(rm))
+    for world in (1, 2, 4, 8):
+        shape = P.strip_shape(world, 2, 3)
+        strip = np.zeros(shape, np.int32)
+        for k in range(8):
+            c, r = P.slot_of(k, world)
+            strip[c, r] = k + 1
+            assert (P.sector(strip, k) == k + 1).all()
+        rm = P.to_row_major(strip)
+        assert rm.shape == (2, 24, 4)
+        for k in range(8):
+            assert (rm[:, 3 * k:3 * k + 3] == k + 1).all()
+        assert torch.equal(P.to_row_major(torch.from_numpy(strip)), torch.from_numpy(rm))
