@@ -65,11 +65,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if N_SECTORS % world != 0:
         raise SystemExit("the sector count (8) must be divisible by the GPU count")
+    # TOPO_BENCH_BACKEND=gloo is a rehearsal switch only (several ranks sharing one GPU on a single-GPU box); the
+    # real multi-GPU run is one rank per GPU over RCCL ("nccl")
+    backend = os.environ.get("TOPO_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
     deg, PW, PH = WORKLOADS[args.workload]
     SW = PW // N_SECTORS
