@@ -170,6 +170,14 @@ float topo_dist_from_depth(float depth);
 /* pad_256                                                                   data/mod.rs:9-11 */
 uint32_t topo_pad_256(uint32_t size);
 
+/* UiController::get_locations_range(location, range_dist)                    control/ui_controller.rs:61-83
+ * (the tile working set around a viewpoint; the reference calls it with 100 000 m).  Writes up
+ * to `cap` (lat_deg, lon_deg) pairs in the reference's order -- sorted by (|lat - c_lat|, |lon - c_lon|), stable over
+ * the row-major cartesian product, where c_lat is always 89 because of the reference's `.min(-90).max(89)` -- and
+ * returns the number of tiles in the range (which may exceed cap).  In the reference the subsequent load order is
+ * that of a HashSet (unspecified); callers here get the sorted order. */
+uint32_t topo_locations_range(float latitude, float longitude, float range_dist, int32_t* out_lat_lon, uint32_t cap);
+
 /* Synthetic COP90-shaped tile for tests and benches (integer-hash fBm): w*h floats. */
 void topo_synth_tile(int32_t lat_deg, int32_t lon_deg, uint32_t w, uint32_t h, uint32_t seed, float* out);
 

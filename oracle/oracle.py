@@ -92,6 +92,15 @@ def srgb_tables():
     return d, t
 
 
+def locations_range(latitude, longitude, range_dist=100_000.0):
+    L = lib()
+    L.oracle_locations_range.restype = C.c_uint32
+    L.oracle_locations_range.argtypes = [C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_uint32]
+    buf = np.zeros((4096, 2), np.int32)
+    n = int(L.oracle_locations_range(latitude, longitude, range_dist, _p(buf), 4096))
+    return [(int(a), int(b)) for a, b in buf[:min(n, 4096)]]
+
+
 def pad_256(n: int) -> int:
     return int(lib().oracle_pad_256(n))
 

@@ -783,6 +783,37 @@ int oracle_visible_peaks(void* p, uint32_t n, const float* peaks_xyz, uint8_t* v
     return 0;
 }
 
+/* UiController::get_locations_range: control/ui_controller.rs:61-83, restated line by line (incl. the
+ * `.min(-90).max(89)` that pins the sort centre's latitude to 89). */
+uint32_t oracle_locations_range(float latitude, float longitude, float range_dist, int32_t* out, uint32_t cap) {
+    int center0 = std::max(std::min((int)floorf(latitude), -90), 89);
+    int center1 = ((int)(floorf(longitude) + 540.0f)) % 360 - 180;
+    float lat_cos = cosf(to_radians_rs(latitude));
+    float arc_factor = 0.5f * range_dist / R0;
+    float arc_factor_sin = sinf(arc_factor);
+    float afs_sq = arc_factor_sin * arc_factor_sin;
+    const float to_deg = 180.0f / 3.14159265358979323846f;
+    float dlon = acosf(1.0f - afs_sq / lat_cos / lat_cos) * to_deg;
+    float dlat = acosf(1.0f - afs_sq) * to_deg;
+    int lat_start = std::max((int)floorf(latitude - dlat), -90);
+    int lat_end = std::min((int)floorf(latitude + dlat), 89);
+    int lon_start = (int)floorf(longitude - dlon);
+    int lon_end = (int)floorf(longitude + dlon);
+    std::vector<std::pair<int, int>> v;
+    for (int lat = lat_start; lat <= lat_end; ++lat)
+        for (int lon = lon_start; lon <= lon_end; ++lon) v.push_back({lat, lon});
+    std::stable_sort(v.begin(), v.end(), [&](const std::pair<int, int>& a, const std::pair<int, int>& b) {
+        return std::make_pair(std::abs(a.first - center0), std::abs(a.second - center1)) <
+               std::make_pair(std::abs(b.first - center0), std::abs(b.second - center1));
+    });
+    uint32_t n = 0;
+    for (auto& p : v) {
+        if (n < cap) { out[2 * n] = p.first; out[2 * n + 1] = (p.second + 540) % 360 - 180; }
+        ++n;
+    }
+    return n;
+}
+
 /* host-side helpers (glam restatement) */
 void oracle_camera_uniforms(const float eye[3], float yaw, float pitch, float fov_y, float width, float height,
                             float sun_theta_deg, float sun_phi_deg, int32_t view_mode, void* out160) {

@@ -107,3 +107,17 @@ def test_synth_numpy_and_cpp_agree(topo):
 def test_sector_fov(topo):
     for sw, sh in ((128, 256), (512, 1024), (1024, 2048), (2048, 4096)):
         assert abs(math.degrees(topo.sector_fov_y(sw, sh)) - 79.2785) < 1e-3
+
+
+def test_locations_range_matches_oracle_and_known_answer(topo, orc):
+    # UiController::get_locations_range (ui_controller.rs:61-83)
+    got = topo.locations_range(45.623, 15.717)
+    assert sorted(got) == [(la, lo) for la in (44, 45, 46) for lo in (14, 15, 16)]          # 0.64 deg x 0.91 deg half-range
+    # sort centre latitude is pinned to 89 by `.min(-90).max(89)`: northern rows first, columns by distance from 15
+    assert got == [(46, 15), (46, 14), (46, 16), (45, 15), (45, 14), (45, 16), (44, 15), (44, 14), (44, 16)]
+    rng = np.random.default_rng(9)
+    for _ in range(300):
+        la, lo = float(rng.uniform(-85, 85)), float(rng.uniform(-179.9, 179.9))
+        rd = float(rng.choice([1.0e4, 1.0e5, 2.5e5]))
+        assert topo.locations_range(la, lo, rd) == orc.locations_range(la, lo, rd), (la, lo, rd)
+    assert topo.locations_range(0.2, 179.8)[0][1] in range(-180, 180)                         # wraps across the antimeridian

@@ -103,6 +103,7 @@ def lib():
             "topo_dist_from_depth": (f32, [f32]),
             "topo_pad_256": (u32, [u32]),
             "topo_synth_tile": (None, [i32, i32, u32, u32, u32, vp]),
+            "topo_locations_range": (u32, [f32, f32, f32, vp, u32]),
         }
         for name, (res, args) in sigs.items():
             fn = getattr(L, name)
@@ -153,6 +154,13 @@ def synth_tile(lat_deg, lon_deg, w=1200, h=1200, seed=synth.SEED_DEFAULT) -> np.
     out = np.empty((h, w), dtype=np.float32)
     lib().topo_synth_tile(lat_deg, lon_deg, w, h, seed & 0xFFFFFFFF, _p(out))
     return out
+
+
+def locations_range(latitude: float, longitude: float, range_dist: float = 100_000.0):
+    """UiController::get_locations_range (ui_controller.rs:61-83): [(lat_deg, lon_deg), ...] in the reference's order."""
+    buf = np.zeros((4096, 2), np.int32)
+    n = int(lib().topo_locations_range(latitude, longitude, range_dist, _p(buf), 4096))
+    return [(int(a), int(b)) for a, b in buf[:min(n, 4096)]]
 
 
 def post_uniforms(width, height, pixelize_n=100.0) -> np.ndarray:

@@ -640,6 +640,40 @@ void camera_uniforms(const float eye_in[3], float yaw, float pitch, float fov_y,
     out->view_mode = view_mode;
 }
 
+// UiController::get_locations_range (control/ui_controller.rs:61-83), f32 as in the reference.
+uint32_t locations_range(float latitude, float longitude, float range_dist, int32_t* out, uint32_t cap) {
+    auto clampi = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
+    (void)clampi;
+    // center.0 = (floor(lat) as i32).min(-90).max(89): always 89, as written
+    int c_lat = (int)floorf(latitude);
+    c_lat = c_lat < -90 ? c_lat : -90;
+    c_lat = c_lat > 89 ? c_lat : 89;
+    const int c_lon = ((int)(floorf(longitude) + 540.0f)) % 360 - 180;
+    const float lat_cos = cosf(rs_to_radians(latitude));
+    const float arc_factor = 0.5f * range_dist / kR0;
+    const float arc_factor_sin = sinf(arc_factor);
+    const float afs_sq = arc_factor_sin * arc_factor_sin;
+    const float R2D = 57.29577951308232f;                       // f32::to_degrees: self * (180 / PI)
+    const float dlon = acosf(1.0f - afs_sq / lat_cos / lat_cos) * R2D;
+    const float dlat = acosf(1.0f - afs_sq) * R2D;
+    int lat_start = (int)floorf(latitude - dlat);
+    lat_start = lat_start > -90 ? lat_start : -90;
+    int lat_end = (int)floorf(latitude + dlat);
+    lat_end = lat_end < 89 ? lat_end : 89;
+    const int lon_start = (int)floorf(longitude - dlon), lon_end = (int)floorf(longitude + dlon);
+    struct Item { int lat, lon, k0, k1; };
+    std::vector<Item> v;
+    for (int la = lat_start; la <= lat_end; ++la)
+        for (int lo = lon_start; lo <= lon_end; ++lo) v.push_back({la, lo, std::abs(la - c_lat), std::abs(lo - c_lon)});
+    std::stable_sort(v.begin(), v.end(), [](const Item& a, const Item& b) { return a.k0 != b.k0 ? a.k0 < b.k0 : a.k1 < b.k1; });
+    uint32_t n = 0;
+    for (const Item& it : v) {
+        if (n < cap && out) { out[2 * n] = it.lat; out[2 * n + 1] = (it.lon + 540) % 360 - 180; }
+        ++n;
+    }
+    return n;
+}
+
 // Synthetic COP90-shaped heights: 5-octave value-noise fBm over global texel coordinates with an integer
 // hash (same definition as topo-renderer_amd/synth.py; f32 ops in the same order).
 namespace {

@@ -127,6 +127,7 @@ void camera_uniforms(const float eye[3], float yaw, float pitch, float fov_y, fl
                      float sun_theta_deg, float sun_phi_deg, int32_t view_mode, topo_uniforms* out);
 void geometry_transform(float h, float lon_deg, float lat_deg, float out[3]);
 void terrain_rotation(float model_lon_deg, float model_lat_deg, float rot3x3_colmajor[9]);
+uint32_t locations_range(float latitude, float longitude, float range_dist, int32_t* out_lat_lon, uint32_t cap);
 void synth_tile(int32_t lat, int32_t lon, uint32_t w, uint32_t h, uint32_t seed, float* out);
 
 }  // namespace topo

@@ -182,6 +182,10 @@ float topo_dist_from_depth(float depth) { return topo::kFar * topo::kNear / (top
 
 uint32_t topo_pad_256(uint32_t size) { return ((size - 1) / 256 + 1) * 256; }
 
+uint32_t topo_locations_range(float latitude, float longitude, float range_dist, int32_t* out, uint32_t cap) {
+    return topo::locations_range(latitude, longitude, range_dist, out, cap);
+}
+
 void topo_synth_tile(int32_t lat, int32_t lon, uint32_t w, uint32_t h, uint32_t seed, float* out) {
     topo::synth_tile(lat, lon, w, h, seed, out);
 }
