@@ -339,3 +339,36 @@ def test_eye_below_the_surface_and_far_above(topo, orc):
         g.update(W, H, u, topo.post_uniforms(W, H))
         o.update(W, H, u, topo.post_uniforms(W, H))
         assert_same_frame(g.render(), o.render(), f"eye dh {dh}")
+
+
+def test_full_size_config4_sectors_against_oracle(topo, orc):
+    # BASELINE config 4 inputs (10x10 degree mosaic = 100 tiles of 1200x1200, 2048x4096 sectors): two of the eight
+    # sectors at full size against the oracle, plus invariance of the result to the occlusion filter
+    import math
+    deg, sw, sh, tile = 10, 2048, 4096, 1200
+    locs = topo.synth.mosaic_locations(40, 10, deg, deg)
+    g, o = topo.TerrainRenderer(sw, sh), orc.OracleRenderer(sw, sh)
+    vlat, vlon = 40 + deg / 2 + 0.123, 10 + deg / 2 + 0.217
+    ground = None
+    for (la, lo) in locs:
+        h = topo.synth_tile(la, lo, tile, tile)
+        if (la, lo) == (int(math.floor(vlat)), int(math.floor(vlon))):
+            ground = topo.synth.height_at(h, la, lo, vlon, vlat)
+        tr = topo.synth.tile_transform(la, lo, tile, tile)
+        g.add_terrain(la, lo, h, *tr)
+        o.add_terrain(la, lo, h, *tr)
+    eye = topo.geometry_transform(ground + 50.0, vlon, vlat)
+    views = topo.panorama_uniforms(eye, 0.0, sw, sh, vlon, vlat, 0)
+    pick = [views[1], views[6]]
+    rg, dg = _strip(topo, g, pick, sw, sh)
+    c_on = g.counters()
+    g.set_occlusion_split(0.0)
+    rg0, dg0 = _strip(topo, g, pick, sw, sh)
+    c_off = g.counters()
+    assert np.array_equal(rg, rg0) and np.array_equal(dg.view(np.uint32), dg0.view(np.uint32))
+    assert c_on["far_tested"] > 10 * c_on["far_survived"] and c_off["far_tested"] == 0
+    assert c_on["blocks_rastered"] < c_off["blocks_rastered"] // 4
+    o.update(sw, sh, pick[0], topo.post_uniforms(sw, sh))
+    ro, do = o.render_views(pick, threads=2)
+    for k in range(2):
+        assert_same_frame((rg[k], dg[k]), (ro[k], do[k]), f"config-4 sector {k}")

@@ -397,14 +397,6 @@ struct FragList {
 constexpr int32_t kInlaneRows = TOPO_INLANE_ROWS, kInlaneCols = TOPO_INLANE_COLS;
 
 __device__ __forceinline__ void frag_push(FragList& fl, uint64_t* __restrict__ vis, uint32_t pix, uint64_t key) {
-#ifdef TOPO_NO_FRAGLIST
-    vis_min(vis + pix, key);
-    return;
-#endif
-#ifdef TOPO_ABL_NOFRAG          // timing ablation only: fragments are computed and dropped
-    asm volatile("" ::"v"(pix), "v"(key));
-    return;
-#endif
     const uint32_t slot = atomicAdd(&fl.count, 1u);
     if (slot < kFragCap) {
         fl.pix[slot] = pix;
@@ -624,12 +616,7 @@ __global__ __launch_bounds__(256, TOPO_RASTER_WAVES) void k_raster(FrameParams P
                 mat4_point(proj, p.x, p.y, p.z, clip);
                 clip_to_screen(clip, (float)P.W, (float)P.H, cur);
             }
-#ifdef TOPO_ABL_NOTRI            // timing ablation only: vertex transform alone
-            asm volatile("" ::"v"(cur.X), "v"(cur.Y), "v"(cur.z), "v"(cur.flag));
-            if (false) {
-#else
             if (r > 0) {
-#endif
                 // cell (i, j) = (x0 + lane, y0 + r - 1): a = (i,j) b = (i,j+1) c = (i+1,j) d = (i+1,j+1)
                 const SVert cc = shfl_down1(prev), d = shfl_down1(cur);
                 // Quad-level reject (result-neutral): if all four corners are plain vertices and their common pixel

@@ -295,16 +295,6 @@ TOPO_HD void interpolate(const VFull& v0, const VFull& v1, const VFull& v2, cons
     wnrm.z = fmaf(v2.wnrm.z, q2, fmaf(v1.wnrm.z, q1, v0.wnrm.z * q0)) * iq;
 }
 
-// Full vs_main for vertex (vx,vy) of tile t under view v.
-TOPO_HD VFull vertex_full(const TileDev& t, uint32_t tile_w, const ViewDev& v, uint32_t vx, uint32_t vy) {
-    VFull o;
-    const size_t idx = (size_t)vy * tile_w + vx;
-    o.wpos = vertex_world(t, vx, vy, TOPO_GLOBAL_F32(t.heights)[idx]);
-    o.wnrm = vertex_normal(t, TOPO_GLOBAL_U32(t.normals)[idx]);
-    mat4_point(v.proj, o.wpos.x, o.wpos.y, o.wpos.z, o.clip);
-    return o;
-}
-
 // Visibility-only version: clip position from the height alone.
 TOPO_HD void vertex_clip(const TileDev& t, const ViewDev& v, uint32_t vx, uint32_t vy, float height, float clip[4]) {
     const f3 p = vertex_world(t, vx, vy, height);
