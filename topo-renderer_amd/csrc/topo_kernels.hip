@@ -303,13 +303,19 @@ __global__ __launch_bounds__(256) void k_occlusion(FrameParams P) {
     for (uint32_t item = wave_global; item < count; item += wave_count) {
         const FarItem fi = P.far[item];
         const uint64_t* vis = P.vis + (size_t)(fi.view_rank >> 16) * P.W * P.H;
+        // footprints are wide and flat: lanes run along x, four rows per round so that four loads are in flight
+        // before the first wave-wide vote
         bool visible = false;
-        for (uint32_t y = fi.y0; y <= fi.y1 && !visible; ++y)
-            for (uint32_t x = fi.x0; x <= fi.x1; x += 64) {
-                const uint32_t px = x + lane;
-                const bool open = px <= fi.x1 && (uint32_t)(vis[(size_t)y * P.W + px] >> 32) >= fi.zmin_bits;
+        for (uint32_t x = fi.x0; x <= fi.x1 && !visible; x += 64) {
+            const uint32_t px = min(x + lane, (uint32_t)fi.x1);       // surplus lanes re-test the last column
+            for (uint32_t y = fi.y0; y <= fi.y1; y += 4) {
+                uint32_t d[4];
+#pragma unroll
+                for (uint32_t k = 0; k < 4; ++k) d[k] = (uint32_t)(vis[(size_t)min(y + k, (uint32_t)fi.y1) * P.W + px] >> 32);
+                const bool open = d[0] >= fi.zmin_bits || d[1] >= fi.zmin_bits || d[2] >= fi.zmin_bits || d[3] >= fi.zmin_bits;
                 if (__any(open)) { visible = true; break; }
             }
+        }
         if (visible && lane == 0) {
             const uint32_t slot = atomicAdd(&P.counters[5], 1u);
             if (slot < P.work_cap) P.work2[slot] = WorkItem{fi.view_rank, fi.block};
