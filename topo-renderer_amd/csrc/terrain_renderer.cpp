@@ -283,7 +283,7 @@ int TerrainRenderer::render_views_device(uint32_t n, const topo_uniforms* views,
     if (work_cap >= (1ull << 30)) return fail(TOPO_ERR_CAPACITY, "too many raster blocks in one submission");
     if (int rc = ensure(&d_vis_, &cap_vis_, pixels * 8)) return rc;
     if (int rc = ensure(&d_views_, &cap_views_, sizeof(ViewDev) * kMaxViewsPerSlot * kViewSlots)) return rc;
-    const size_t near_cap = 4 * work_cap;   // a near block is cut into up to 4 strips
+    const size_t near_cap = 8 * work_cap;   // a near block is cut into strips of >= 2 cell rows: at most 8
     if (int rc = ensure(&d_work_, &cap_work_, (near_cap ? near_cap : 1) * sizeof(WorkItem))) return rc;
     if (int rc = ensure(&d_work2_, &cap_work2_, (work_cap ? work_cap : 1) * sizeof(WorkItem))) return rc;
     if (int rc = ensure(&d_far_, &cap_far_, (work_cap ? work_cap : 1) * sizeof(FarItem))) return rc;

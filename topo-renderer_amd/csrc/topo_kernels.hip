@@ -168,6 +168,11 @@ __global__ __launch_bounds__(256) void k_clear(uint64_t* __restrict__ vis, size_
 // Conservative frustum test of one raster block against one view, in f64.  A block is kept unless its
 // bounding sphere (inflated by 64 m for the f32 noise of the real vertex path) lies wholly outside one of
 // the six clip planes of camera_proj.  Culling is result-neutral: culled blocks cannot produce fragments.
+#ifndef TOPO_NEAR_STRIP
+#define TOPO_NEAR_STRIP 4
+#endif
+constexpr uint32_t kStrip = TOPO_NEAR_STRIP;      // cell rows per near-block strip (terrain_renderer.cpp sizes the list for >= 2)
+
 struct SinCos64 { double s, c; };
 __device__ __forceinline__ SinCos64 sincos64(double a) { SinCos64 r; r.s = sin(a); r.c = cos(a); return r; }
 
@@ -278,14 +283,14 @@ __global__ __launch_bounds__(256) void k_cull(FrameParams P) {
         }
     }
     // a near block: with the occlusion filter on these are few and heavy (large triangles), so each is cut into
-    // strips of 4 cell rows to spread them over the resident waves.  block = id | first cell row << 24 | rows << 28
+    // strips of kStrip cell rows to spread them over the resident waves.  block = id | first cell row << 24 | rows << 28
     if (P.split_m > 0.0f) {
         const uint32_t cell_rows = min(kBCY, P.tile_h - 1 - by * kBCY);
-        const uint32_t n = (cell_rows + 3) / 4;
+        const uint32_t n = (cell_rows + kStrip - 1) / kStrip;
         const uint32_t base = atomicAdd(&P.counters[0], n);
         for (uint32_t k = 0; k < n; ++k)
             if (base + k < P.near_cap)
-                P.work[base + k] = WorkItem{(view << 16) | rank, blk | ((4 * k) << 24) | (min(4u, cell_rows - 4 * k) << 28)};
+                P.work[base + k] = WorkItem{(view << 16) | rank, blk | ((kStrip * k) << 24) | (min(kStrip, cell_rows - kStrip * k) << 28)};
         return;
     }
     const uint32_t slot = atomicAdd(&P.counters[0], 1u);
