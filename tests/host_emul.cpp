@@ -28,6 +28,8 @@ static TileDev make_dev(const EmulTile& e) {
     return t;
 }
 
+uint32_t emul_fastdiv(uint32_t n, uint32_t d) { return fastdiv(n, fastdiv_make(d)); }
+void emul_markstein_div(const float* x, float C, float* out, size_t n) { for (size_t i = 0; i < n; ++i) out[i] = markstein_div(x[i], C, 1.0f / C); }
 void emul_sincos(const float* x, float* s, float* c, size_t n) { for (size_t i = 0; i < n; ++i) sincos_f(x[i], s[i], c[i]); }
 
 void emul_normals_interior(const EmulTile* e, int W, int H) {
@@ -95,7 +97,19 @@ int emul_render(const EmulTile* tiles, uint32_t n_tiles, uint32_t tile_w, uint32
     memcpy(view.sun, uniforms40 + 36, 12);
     memcpy(&view.view_mode, uniforms40 + 39, 4);
     std::vector<TileDev> td;
-    for (uint32_t i = 0; i < n_tiles; ++i) td.push_back(make_dev(tiles[i]));
+    std::vector<std::vector<float>> trig(n_tiles);          // what k_block_minmax tabulates in the load phase
+    float ndec[256];                                         // what k_resolve tabulates in LDS
+    for (uint32_t c = 0; c < 256; ++c) ndec[c] = normal_channel(c);
+    for (uint32_t i = 0; i < n_tiles; ++i) {
+        TileDev t = make_dev(tiles[i]);
+        trig[i].resize(2 * (size_t)(tile_w + tile_h));
+        for (uint32_t x = 0; x < tile_w; ++x) sincos_f(vertex_lon(t, x), trig[i][2 * x], trig[i][2 * x + 1]);
+        for (uint32_t y = 0; y < tile_h; ++y) sincos_f(vertex_lat(t, y), trig[i][2 * (tile_w + y)], trig[i][2 * (tile_w + y) + 1]);
+        t.trig_lon = trig[i].data();
+        t.trig_lat = trig[i].data() + 2 * (size_t)tile_w;
+        td.push_back(t);
+    }
+    const FastDiv div_hm1 = fastdiv_make(tile_h - 1), div_tris = fastdiv_make(2u * (tile_w - 1) * (tile_h - 1));
     std::vector<uint64_t> vis((size_t)W * H, kVisClear);
     const uint32_t tris_per_tile = 2u * (tile_w - 1) * (tile_h - 1);
     for (uint32_t rank = 0; rank < n_tiles; ++rank) {
@@ -120,7 +134,7 @@ int emul_render(const EmulTile* tiles, uint32_t n_tiles, uint32_t tile_w, uint32
                 if (nnear != 0) {
                     for (uint32_t fan = 0; fan < 2; ++fan) {
                         ResolvedTri r;
-                        if (resolve_triangle(t, tile_w, tile_h, view, W, H, tri, fan, r)) emul_emit(r.ts, vis.data(), W, (draw << 1) | fan);
+                        if (resolve_triangle(t, tile_w, div_hm1, tile_h - 1, view, W, H, tri, fan, r)) emul_emit(r.ts, vis.data(), W, (draw << 1) | fan);
                     }
                     continue;
                 }
@@ -142,9 +156,9 @@ int emul_render(const EmulTile* tiles, uint32_t n_tiles, uint32_t tile_w, uint32
         const uint32_t id = (uint32_t)key;
         float lin[4] = {0.0f, 0.71f, 0.885f, 1.0f};
         if (id != kNoTri) {
-            const uint32_t draw = id >> 1, fan = id & 1u, rank = draw / tris_per_tile, tri = draw - rank * tris_per_tile;
+            const uint32_t draw = id >> 1, fan = id & 1u, rank = fastdiv(draw, div_tris), tri = draw - rank * tris_per_tile;
             ResolvedTri r; float b[3];
-            if (!(resolve_vertices(td[rank], tile_w, tile_h, view, W, H, tri, fan, r) && triangle_bary(r.s[0], r.s[1], r.s[2], px, py, b))) return -1;
+            if (!(resolve_vertices(td[rank], tile_w, div_hm1, tile_h - 1, view, W, H, tri, fan, ndec, r) && triangle_bary(r.s[0], r.s[1], r.s[2], px, py, b))) return -1;
             f3 wpos, wnrm;
             interpolate(r.v[0], r.v[1], r.v[2], b, wpos, wnrm);
             shade_fragment(view.view_mode, {view.sun[0], view.sun[1], view.sun[2]}, view.cam_x, view.cam_y, (float)px + 0.5f,

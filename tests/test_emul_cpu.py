@@ -31,6 +31,44 @@ def test_from_unorm8_is_the_exact_quotient():
         assert np.float32(L.emul_from_unorm8(c)) == np.float32(c) / np.float32(255.0)
 
 
+def test_constant_division():
+    """div_const's device form (one Markstein correction of x * RN(1/C)) is the IEEE quotient: for C = 255 at every
+    magnitude, for C = 0.15f - 0.05f inside 2^-97 .. 2^123 (an exhaustive sweep of all 2^32 inputs was run once when the
+    form was introduced; this is a dense sample of the same claim)."""
+    import ctypes as C
+    L = emul.lib()
+    L.emul_markstein_div.argtypes = [C.c_void_p, C.c_float, C.c_void_p, C.c_size_t]
+    rng = np.random.default_rng(3)
+    n = 4_000_000
+    mant = rng.integers(0, 1 << 23, n, dtype=np.uint32)
+    sign = rng.integers(0, 2, n, dtype=np.uint32) << 31
+    for c, lo, hi in ((np.float32(255.0), 1, 254), (np.float32(0.15) - np.float32(0.05), 30, 249)):
+        expo = rng.integers(lo, hi + 1, n, dtype=np.uint32) << 23
+        x = (sign | expo | mant).view(np.float32)
+        x[:4] = [0.0, 1.0, -1.0, 0.05]
+        out = np.empty_like(x)
+        L.emul_markstein_div(x.ctypes.data, float(c), out.ctypes.data, n)
+        with np.errstate(all="ignore"):
+            ref = x / c
+        assert np.array_equal(out.view(np.uint32), ref.view(np.uint32))
+
+
+def test_fastdiv_is_exact():
+    import ctypes as C
+    L = emul.lib()
+    L.emul_fastdiv.restype = C.c_uint32
+    L.emul_fastdiv.argtypes = [C.c_uint32, C.c_uint32]
+    rng = np.random.default_rng(4)
+    ds = [2, 3, 7, 8, 1199, 1200, 3599, 2 * 1199 * 1199, 2 * 3599 * 3599, (1 << 30) + 1, (1 << 31) - 1] + list(rng.integers(2, 1 << 31, 40))
+    for d in ds:
+        d = int(d)
+        ns = {0, 1, d - 1, d, d + 1, 2 * d - 1, 2 * d, (1 << 31) - 1, ((1 << 31) - 1) // d * d, max(((1 << 31) - 1) // d * d - 1, 0)}
+        ns |= {int(v) for v in rng.integers(0, 1 << 31, 200)}
+        for nn in ns:
+            if nn < (1 << 31):
+                assert L.emul_fastdiv(nn, d) == nn // d, (nn, d)
+
+
 def test_vis_key_orders_like_less_then_draw_order():
     L = emul.lib()
     import ctypes as C

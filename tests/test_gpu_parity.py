@@ -27,6 +27,35 @@ def test_device_sincos_matches_spec(topo, orc):
     assert np.abs(s - np.sin(x.astype(np.float64))).max() < 2e-7
 
 
+def test_division_probe(topo):
+    """The device's division forms (topo_math.h: div_f, div_const) against the IEEE quotient numpy computes."""
+    r = topo.TerrainRenderer(8, 8)
+    rng = np.random.default_rng(7)
+    n = 2_000_000
+    mant = lambda: rng.uniform(1.0, 2.0, n).astype(np.float32) * rng.choice([-1.0, 1.0], n).astype(np.float32)
+    # general form: operands and quotients well inside 2^-96 .. 2^96 (the range this path uses is far narrower)
+    x = mant() * np.exp2(rng.integers(-40, 41, n)).astype(np.float32)
+    y = mant() * np.exp2(rng.integers(-40, 41, n)).astype(np.float32)
+    x[:1000] = 1.0                                        # reciprocals
+    x[1000:2000] = 0.0
+    y[2000:3000] = np.arange(1, 1001, dtype=np.float32)   # small integers (doubled areas)
+    q = r.probe_div(0, x, y)
+    with np.errstate(all="ignore"):
+        ref = x / y
+    assert np.array_equal(q, ref)                         # == : the sign of a zero quotient is not preserved
+    assert np.array_equal(q[q != 0].view(np.uint32), ref[ref != 0].view(np.uint32))
+    # same divisor shared by several numerators, the perspective and area reciprocals
+    w = rng.uniform(50.0, 1.0e6, n).astype(np.float32)
+    assert np.array_equal(r.probe_div(0, np.ones_like(w), w).view(np.uint32), (np.float32(1.0) / w).view(np.uint32))
+    # constants: x / 255 (dither) and x / 0.1 (contour), any magnitude the path can produce
+    xs = np.concatenate([rng.uniform(-2.0, 2.0, n), rng.uniform(-1e-6, 1e-6, 1000), [0.0, 1.0, -1.0, 2.0 ** -24]]).astype(np.float32)
+    for kind, c in ((1, np.float32(255.0)), (2, np.float32(0.15) - np.float32(0.05))):
+        got = r.probe_div(kind, xs, xs)
+        assert np.array_equal(got, xs / c)
+        nz = got != 0
+        assert np.array_equal(got[nz].view(np.uint32), (xs / c)[nz].view(np.uint32))
+
+
 @pytest.mark.parametrize("tile,n_lat,n_lon", [(64, 1, 1), (48, 2, 2), (33, 3, 3), (150, 1, 2)])
 def test_normals_byte_exact(topo, orc, tile, n_lat, n_lon):
     sc = Scene(tile, n_lat, n_lon)

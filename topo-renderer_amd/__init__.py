@@ -95,6 +95,7 @@ def lib():
             "topo_set_occlusion_split": (C.c_int, [vp, f32]),
             "topo_read_normals": (C.c_int, [vp, i32, i32, vp]),
             "topo_probe_sincos": (C.c_int, [vp, vp, vp, vp, sz]),
+            "topo_probe_div": (C.c_int, [vp, i32, vp, vp, vp, sz]),
             "topo_visible_peaks": (C.c_int, [vp, u32, vp, vp, vp]),
             "topo_visible_peaks_device": (C.c_int, [vp, vp, u32, u32, vp, sz, u32, vp, vp, vp]),
             "topo_camera_uniforms": (None, [vp, f32, f32, f32, f32, f32, f32, f32, i32, vp]),
@@ -305,6 +306,13 @@ class TerrainRenderer:
         u = np.ascontiguousarray(uniforms).view(np.uint8)
         self._check(lib().topo_visible_peaks_device(self._h, _p(u), width, height, C.c_void_p(depth_ptr), depth_pitch, n,
                                                     C.c_void_p(peaks_ptr), C.c_void_p(visible_ptr), C.c_void_p(xy_ptr)))
+
+    def probe_div(self, kind: int, x: np.ndarray, y: np.ndarray) -> np.ndarray:
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        y = np.ascontiguousarray(y, dtype=np.float32)
+        out = np.empty_like(x)
+        self._check(lib().topo_probe_div(self._h, kind, _p(x), _p(y), _p(out), x.size))
+        return out
 
     def probe_sincos(self, x: np.ndarray):
         x = np.ascontiguousarray(x, dtype=np.float32)

@@ -169,7 +169,8 @@ int TerrainRenderer::add_terrain(int32_t lat, int32_t lon, const float* heights,
     t.seq = next_seq_++;
     TOPO_HIP_TRY(hipMalloc((void**)&t.d_heights, texels * 4));
     hipError_t e = hipMalloc((void**)&t.d_normals, texels * 4);
-    if (e == hipSuccess) e = hipMalloc((void**)&t.d_minmax, (size_t)bxc * byc * 2 * sizeof(float));
+    // one allocation: block min/max (2 floats per block), then the sin/cos tables of the w columns and the h rows
+    if (e == hipSuccess) e = hipMalloc((void**)&t.d_minmax, ((size_t)bxc * byc * 2 + 2 * ((size_t)w + h)) * sizeof(float));
     if (e == hipSuccess) e = hipMemcpyAsync(t.d_heights, heights, texels * 4, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream_);
     // (the zero-initialised normal texture: k_normals_interior writes the untouched border ring as zero)
     if (e != hipSuccess) {
@@ -180,11 +181,13 @@ int TerrainRenderer::add_terrain(int32_t lat, int32_t lon, const float* heights,
     t.dev.heights = t.d_heights;
     t.dev.normals = t.d_normals;
     t.dev.block_minmax = t.d_minmax;
+    t.dev.trig_lon = t.d_minmax + (size_t)bxc * byc * 2;
+    t.dev.trig_lat = t.dev.trig_lon + 2 * (size_t)w;
     t.dev.raster_x = rp[0]; t.dev.raster_y = rp[1];
     t.dev.model_x = mp[0]; t.dev.model_y = mp[1];
     t.dev.scale_x = ps[0]; t.dev.scale_y = ps[1];
     terrain_rotation(mp[0], mp[1], t.dev.rot);
-    launch_block_minmax(t.d_heights, t.d_minmax, w, h, stream_);
+    launch_block_minmax(t.dev, w, h, stream_);
     // BTreeMap::insert replaces an existing entry; its GPU resources are dropped after the passes below
     Tile old{};
     bool had_old = false;
@@ -340,7 +343,9 @@ int TerrainRenderer::render_views_device(uint32_t n, const topo_uniforms* views,
     p.tile_h = tile_h_;
     p.bx_count = bxc;
     p.by_count = byc;
-    p.tris_per_tile = n_tiles ? 2u * (tile_w_ - 1) * (tile_h_ - 1) : 1u;
+    p.tris_per_tile = n_tiles ? 2u * (tile_w_ - 1) * (tile_h_ - 1) : 8u;
+    p.div_tris = fastdiv_make(p.tris_per_tile);
+    p.div_hm1 = fastdiv_make(n_tiles ? tile_h_ - 1 : 2u);
     {   // the cleared render target texel: Color{0, 0.71, 0.885, 1} (terrain_renderer.rs:379-384) stored as Rgba8UnormSrgb
         float thresh[256];
         for (int i = 0; i < 256; ++i) thresh[i] = bits_f(TOPO_SRGB_THRESH_BITS[i]);
@@ -499,7 +504,7 @@ int TerrainRenderer::get_timings(float out[TOPO_TIMING_SLOTS]) {
     return TOPO_OK;
 }
 
-int TerrainRenderer::get_counters(uint32_t out[4]) {
+int TerrainRenderer::get_counters(uint32_t out[6]) {
     for (int i = 0; i < 6; ++i) out[i] = 0;
     if (!d_counters_) return TOPO_OK;
     if (int rc = bind_device()) return rc;
@@ -531,6 +536,22 @@ int TerrainRenderer::probe_sincos(const float* x, float* s, float* c, size_t n) 
     TOPO_HIP_TRY(hipMemcpy(s, ds, n * 4, hipMemcpyDeviceToHost));
     TOPO_HIP_TRY(hipMemcpy(c, dc, n * 4, hipMemcpyDeviceToHost));
     (void)hipFree(dx); (void)hipFree(ds); (void)hipFree(dc);
+    return TOPO_OK;
+}
+
+int TerrainRenderer::probe_div(int32_t kind, const float* x, const float* y, float* out, size_t n) {
+    if (kind < 0 || kind > 2 || !x || !y || !out) return fail(TOPO_ERR_INVALID, "probe_div: bad argument");
+    if (int rc = bind_device()) return rc;
+    float *dx = nullptr, *dy = nullptr, *dq = nullptr;
+    TOPO_HIP_TRY(hipMalloc((void**)&dx, n * 4));
+    TOPO_HIP_TRY(hipMalloc((void**)&dy, n * 4));
+    TOPO_HIP_TRY(hipMalloc((void**)&dq, n * 4));
+    TOPO_HIP_TRY(hipMemcpy(dx, x, n * 4, hipMemcpyHostToDevice));
+    TOPO_HIP_TRY(hipMemcpy(dy, y, n * 4, hipMemcpyHostToDevice));
+    launch_probe_div(kind, dx, dy, dq, n, stream_);
+    TOPO_HIP_TRY(hipStreamSynchronize(stream_));
+    TOPO_HIP_TRY(hipMemcpy(out, dq, n * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(dq);
     return TOPO_OK;
 }
 

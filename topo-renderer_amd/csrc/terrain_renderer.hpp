@@ -56,6 +56,7 @@ class TerrainRenderer {
     int set_occlusion_split(float metres);
     int read_normals(int32_t lat, int32_t lon, uint8_t* out);
     int probe_sincos(const float* x, float* s, float* c, size_t n);
+    int probe_div(int32_t kind, const float* x, const float* y, float* out, size_t n);
     int visible_peaks(uint32_t n, const float* peaks, uint8_t* visible, uint32_t* xy);
     int visible_peaks_device(const topo_uniforms* view, uint32_t w, uint32_t h, const float* depth_dev, size_t depth_pitch,
                              uint32_t n, const float* peaks_dev, uint8_t* visible_dev, uint32_t* xy_dev);

@@ -158,6 +158,11 @@ int topo_probe_sincos(topo_ctx* ctx, const float* x, float* s, float* c, size_t 
     TOPO_CALL(ctx->r->probe_sincos(x, s, c, n));
 }
 
+int topo_probe_div(topo_ctx* ctx, int32_t kind, const float* x, const float* y, float* out, size_t n) {
+    TOPO_GUARD(ctx);
+    TOPO_CALL(ctx->r->probe_div(kind, x, y, out, n));
+}
+
 void topo_camera_uniforms(const float eye[3], float yaw, float pitch, float fov_y, float width, float height,
                           float sun_theta_deg, float sun_phi_deg, int32_t view_mode, topo_uniforms* out) {
     topo::camera_uniforms(eye, yaw, pitch, fov_y, width, height, sun_theta_deg, sun_phi_deg, view_mode, out);

@@ -57,6 +57,7 @@ struct FrameParams {
     uint32_t tile_w, tile_h;
     uint32_t bx_count, by_count;
     uint32_t tris_per_tile;
+    FastDiv div_tris, div_hm1;   // exact division by tris_per_tile / (tile_h - 1)
     uint32_t sky_c8;           // the cleared render-target texel (sRGB8-encoded clear colour)
 };
 
@@ -83,7 +84,7 @@ struct CornerJob {         // compute_normals_corner (compute_normals_corner_sha
     uint32_t uni;
 };
 
-void launch_block_minmax(const float* heights, float* minmax, uint32_t w, uint32_t h, hipStream_t s);
+void launch_block_minmax(const TileDev& tile, uint32_t w, uint32_t h, hipStream_t s);   // + the tile's sin/cos tables
 // interior normals of tiles[first .. first+count); also zeroes their border ring (fresh Rgba8Unorm texture)
 void launch_normals_interior(const TileDev* tiles, uint32_t first, uint32_t count, uint32_t w, uint32_t h, int lds_rows,
                              hipStream_t s);
@@ -106,5 +107,6 @@ void launch_visible_peaks(const float* proj16_dev, uint32_t w, uint32_t h, const
 
 // unit-test probes
 void launch_probe_sincos(const float* x, float* s, float* c, size_t n, hipStream_t st);
+void launch_probe_div(int kind, const float* x, const float* y, float* out, size_t n, hipStream_t st);
 
 }  // namespace topo

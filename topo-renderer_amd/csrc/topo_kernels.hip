@@ -27,9 +27,9 @@ __device__ __forceinline__ void vis_min(uint64_t* p, uint64_t key) {
 // load phase
 // ======================================================================================================
 
-// min/max height of the (kVX x kVY) vertices of every raster block; one wave per block.
-__global__ __launch_bounds__(64) void k_block_minmax(const float* __restrict__ heights, float* __restrict__ minmax,
-                                                     uint32_t w, uint32_t h, uint32_t bx_count) {
+// min/max height of the (kVX x kVY) vertices of every raster block, one wave per block; the first (w + h) / 64
+// waves also fill one entry each of the tile's sin/cos tables (TileDev::trig_lon / trig_lat).
+__global__ __launch_bounds__(64) void k_block_minmax(TileDev t, uint32_t w, uint32_t h, uint32_t bx_count) {
     const uint32_t blk = blockIdx.x, bx = blk % bx_count, by = blk / bx_count;
     const uint32_t x = bx * kBCX + threadIdx.x;
     float mn = INFINITY, mx = -INFINITY;
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(64) void k_block_minmax(const float* __restrict__ h
         for (uint32_t r = 0; r < kVY; ++r) {
             const uint32_t y = by * kBCY + r;
             if (y >= h) break;
-            const float v = heights[(size_t)y * w + x];
+            const float v = t.heights[(size_t)y * w + x];
             mn = fminf(mn, v);
             mx = fmaxf(mx, v);
         }
@@ -47,9 +47,22 @@ __global__ __launch_bounds__(64) void k_block_minmax(const float* __restrict__ h
         mn = fminf(mn, __shfl_xor(mn, off));
         mx = fmaxf(mx, __shfl_xor(mx, off));
     }
+    float* minmax = const_cast<float*>(t.block_minmax);
     if (threadIdx.x == 0) {
         minmax[2 * blk] = mn;
         minmax[2 * blk + 1] = mx;
+    }
+    for (uint32_t e = blk * 64 + threadIdx.x; e < w + h; e += gridDim.x * 64) {
+        float sn, cs;
+        if (e < w) {
+            sincos_f(vertex_lon(t, e), sn, cs);
+            const_cast<float*>(t.trig_lon)[2 * e] = sn;
+            const_cast<float*>(t.trig_lon)[2 * e + 1] = cs;
+        } else {
+            sincos_f(vertex_lat(t, e - w), sn, cs);
+            const_cast<float*>(t.trig_lat)[2 * (e - w)] = sn;
+            const_cast<float*>(t.trig_lat)[2 * (e - w) + 1] = cs;
+        }
     }
 }
 
@@ -480,7 +493,7 @@ __device__ __forceinline__ void raster_rows(FragList& fl, uint64_t* __restrict__
     // hardware reciprocal (v_rcp_f32) is plenty for the span ESTIMATE
     const float i0 = m0 ? __builtin_amdgcn_rcpf((float)m0) : 0.0f, i1 = m1 ? __builtin_amdgcn_rcpf((float)m1) : 0.0f,
                 i2 = m2 ? __builtin_amdgcn_rcpf((float)m2) : 0.0f;
-    const float iA = 1.0f / (float)(-area2);
+    const float iA = div_f(1.0f, (float)(-area2));
     const float dz1 = z1 - z0, dz2 = z2 - z0;
     const int32_t nx = px1 - px0;
     for (int32_t py = py0; py <= py1; ++py) {
@@ -681,11 +694,11 @@ __global__ __launch_bounds__(256) void k_raster_rare(FrameParams P) {
     if (count > P.rare_cap) count = P.rare_cap;
     for (uint32_t item = P.counters[7] + blockIdx.x * blockDim.x + threadIdx.x; item < count; item += gridDim.x * blockDim.x) {
         const RareItem ri = P.rare[item];
-        const uint32_t rank = ri.draw / P.tris_per_tile, tri = ri.draw - rank * P.tris_per_tile;
+        const uint32_t rank = fastdiv(ri.draw, P.div_tris), tri = ri.draw - rank * P.tris_per_tile;
         uint64_t* vis = P.vis + (size_t)ri.view * P.W * P.H;
         for (uint32_t fan = 0; fan < 2; ++fan) {
             ResolvedTri r;
-            if (!resolve_triangle(P.tiles[rank], P.tile_w, P.tile_h, P.views[ri.view], P.W, P.H, tri, fan, r)) continue;
+            if (!resolve_triangle(P.tiles[rank], P.tile_w, P.div_hm1, P.tile_h - 1, P.views[ri.view], P.W, P.H, tri, fan, r)) continue;
             const TriSetup& ts = r.ts;
             const uint32_t id = (ri.draw << 1) | fan;
             const int32_t nx = ts.px1 - ts.px0 + 1, ny = ts.py1 - ts.py0 + 1;
@@ -737,7 +750,7 @@ __global__ __launch_bounds__(256) void k_raster_big(FrameParams P) {
             const int32_t b0 = ((dy0 > 0) || (dy0 == 0 && dx0 < 0)) ? 0 : -1;
             const int32_t b1 = ((dy1 > 0) || (dy1 == 0 && dx1 < 0)) ? 0 : -1;
             const int32_t b2 = ((dy2 > 0) || (dy2 == 0 && dx2 < 0)) ? 0 : -1;
-            const float iA = 1.0f / (float)(-area2);
+            const float iA = div_f(1.0f, (float)(-area2));
             const float z0 = bi.z[0], dz1 = bi.z[1] - bi.z[0], dz2 = bi.z[2] - bi.z[0];
             for (int32_t sy = py0 & ~7; sy <= py1; sy += 8)
                 for (int32_t sx = px0 & ~7; sx <= px1; sx += 32) {
@@ -802,9 +815,11 @@ __device__ __forceinline__ float vis_depth(const uint64_t* vis, int32_t W, int32
 __global__ __launch_bounds__(256) void k_resolve(FrameParams P, OutputParams O) {
     __shared__ float s_thresh[256];
     __shared__ float s_decode[256];
+    __shared__ float s_ndec[256];      // normal channel decode 2c/255 - 1
     __shared__ float s_lin[6][66];     // linear depth of the 64x4 pixel block + 1 px halo (clamp-to-edge)
     s_thresh[threadIdx.x] = bits_f(TOPO_SRGB_THRESH_BITS[threadIdx.x]);
     s_decode[threadIdx.x] = bits_f(TOPO_SRGB_DECODE_BITS[threadIdx.x]);
+    s_ndec[threadIdx.x] = normal_channel(threadIdx.x);
     const uint32_t view_idx = blockIdx.z;
     const uint64_t* vis = P.vis + (size_t)view_idx * P.W * P.H;
     const int32_t bx = blockIdx.x * 64, by = blockIdx.y * 4;
@@ -825,10 +840,10 @@ __global__ __launch_bounds__(256) void k_resolve(FrameParams P, OutputParams O) 
     if (id != kNoTri) {
         float lin[4] = {0.0f, 0.71f, 0.885f, 1.0f};
         const uint32_t draw = id >> 1, fan = id & 1u;
-        const uint32_t rank = draw / P.tris_per_tile, tri = draw - rank * P.tris_per_tile;
+        const uint32_t rank = fastdiv(draw, P.div_tris), tri = draw - rank * P.tris_per_tile;
         ResolvedTri r;
         float b[3];
-        if (resolve_vertices(P.tiles[rank], P.tile_w, P.tile_h, view, P.W, P.H, tri, fan, r) &&
+        if (resolve_vertices(P.tiles[rank], P.tile_w, P.div_hm1, P.tile_h - 1, view, P.W, P.H, tri, fan, s_ndec, r) &&
             triangle_bary(r.s[0], r.s[1], r.s[2], px, py, b)) {
             f3 wpos, wnrm;
             interpolate(r.v[0], r.v[1], r.v[2], b, wpos, wnrm);
@@ -879,15 +894,21 @@ __global__ void k_probe_sincos(const float* x, float* s, float* c, size_t n) {
     if (i < n) sincos_f(x[i], s[i], c[i]);
 }
 
+__global__ void k_probe_div(int kind, const float* x, const float* y, float* out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = kind == 0 ? div_f(x[i], y[i]) : kind == 1 ? div_const(x[i], 255.0f, 1.0f / 255.0f) : div_const(x[i], 0.15f - 0.05f, 1.0f / (0.15f - 0.05f));
+}
+
 }  // namespace
 
 // ======================================================================================================
 // launchers
 // ======================================================================================================
 
-void launch_block_minmax(const float* heights, float* minmax, uint32_t w, uint32_t h, hipStream_t s) {
+void launch_block_minmax(const TileDev& tile, uint32_t w, uint32_t h, hipStream_t s) {
     const uint32_t bxc = (w - 1 + kBCX - 1) / kBCX, byc = (h - 1 + kBCY - 1) / kBCY;
-    hipLaunchKernelGGL(k_block_minmax, dim3(bxc * byc), dim3(64), 0, s, heights, minmax, w, h, bxc);
+    hipLaunchKernelGGL(k_block_minmax, dim3(bxc * byc), dim3(64), 0, s, tile, w, h, bxc);
 }
 
 void launch_normals_interior(const TileDev* tiles, uint32_t first, uint32_t count, uint32_t w, uint32_t h, int lds_rows,
@@ -977,6 +998,10 @@ void launch_visible_peaks(const float* proj16_dev, uint32_t w, uint32_t h, const
 
 void launch_probe_sincos(const float* x, float* s, float* c, size_t n, hipStream_t st) {
     hipLaunchKernelGGL(k_probe_sincos, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, s, c, n);
+}
+
+void launch_probe_div(int kind, const float* x, const float* y, float* out, size_t n, hipStream_t st) {
+    hipLaunchKernelGGL(k_probe_div, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, kind, x, y, out, n);
 }
 
 }  // namespace topo

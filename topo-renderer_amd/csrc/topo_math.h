@@ -69,6 +69,70 @@ TOPO_HD float bits_f(uint32_t u) {
 // WGSL radians()
 TOPO_HD float deg2rad(float d) { return d * 0.017453292519943295f; }
 
+// ---- division -------------------------------------------------------------------------------------
+// The spec's divisions are IEEE-754 quotients.  On the GPU the compiler expands `/` into a Newton-Raphson core
+// wrapped in range handling (2x v_div_scale, v_div_fmas, v_div_fixup: 11 instructions); every division of this
+// path has operands and quotient far inside the exponent range (|x|, |y|, |x/y| within 2^-96 .. 2^96, stated at
+// the call sites), where the scaling is the identity and the core alone yields the same bits.  The core is
+// written out below for the device; the g++ build (tests/host_emul.cpp) uses the plain operator, and the GPU
+// parity tests plus tests/test_gpu_parity.py::test_division_probe compare the two.  Not preserved: the sign of a
+// zero quotient (-0/y gives +0); no consumer of these quotients can tell the two zeros apart.
+struct Recip {   // a divisor and its refined reciprocal, shared by all quotients with that divisor
+    float y, r;
+};
+TOPO_HD Recip recip_of(float y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float a = __builtin_amdgcn_rcpf(y);             // 1 ulp
+    return {y, fmaf(fmaf(-y, a, 1.0f), a, a)};            // one Newton-Raphson step
+#else
+    return {y, 0.0f};
+#endif
+}
+TOPO_HD float div_by(float x, Recip d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float q = x * d.r;
+    q = fmaf(fmaf(-d.y, q, x), d.r, q);
+    return fmaf(fmaf(-d.y, q, x), d.r, q);
+#else
+    return x / d.y;
+#endif
+}
+TOPO_HD float div_f(float x, float y) { return div_by(x, recip_of(y)); }
+// x / C for a constant C whose correctly rounded reciprocal RC is known: one Markstein correction of x * RC.
+// Exhaustively checked against the IEEE quotient for C = 255 (every finite x) and C = 0.15f - 0.05f
+// (2^-97 <= |x| < 2^123 and 0), see tests/test_emul_cpu.py::test_constant_division.
+TOPO_HD float markstein_div(float x, float C, float RC) {
+    const float q = x * RC;
+    return fmaf(fmaf(-q, C, x), RC, q);
+}
+TOPO_HD float div_const(float x, float C, float RC) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return markstein_div(x, C, RC);
+#else
+    (void)RC;
+    return x / C;
+#endif
+}
+
+// Exact unsigned division by a run-time constant (n < 2^31, 2 <= d < 2^31): q = (n * m) >> (31 + l) with
+// l = ceil(log2 d), m = ceil(2^(31+l) / d) < 2^32 (Granlund & Montgomery 1994, Theorem 4.2 with N = 31).
+struct FastDiv {
+    uint32_t m, s;   // multiplier, shift - 32
+};
+inline FastDiv fastdiv_make(uint32_t d) {
+    uint32_t l = 0;
+    while ((1ull << l) < d) ++l;
+    const uint64_t num = 1ull << (31 + l);
+    return {(uint32_t)((num + d - 1) / d), l - 1};
+}
+TOPO_HD uint32_t fastdiv(uint32_t n, FastDiv f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umulhi(n, f.m) >> f.s;
+#else
+    return (uint32_t)(((uint64_t)n * f.m) >> 32) >> f.s;
+#endif
+}
+
 // sin & cos of x (|x| < ~1e4): k = rint(x*2/pi); r = x - k*pi/2 in three fma steps (Cody-Waite);
 // Cephes sinf/cosf kernels on |r| <= pi/4 in fma Horner form; quadrant swap.
 TOPO_HD void sincos_f(float x, float& sn, float& cs) {
@@ -100,9 +164,9 @@ TOPO_HD float cos_f(float x) {
 
 TOPO_HD float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 TOPO_HD f3 cross3(f3 a, f3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
-TOPO_HD f3 normalize3(f3 a) {
-    const float len = sqrtf(dot3(a, a));
-    return {a.x / len, a.y / len, a.z / len};
+TOPO_HD f3 normalize3(f3 a) {   // |a| is 0.3 .. 2 on this path (interpolated unit-ish normals, stencil cross products > 1 m^2)
+    const Recip len = recip_of(sqrtf(dot3(a, a)));
+    return {div_by(a.x, len), div_by(a.y, len), div_by(a.z, len)};
 }
 TOPO_HD float fract_f(float x) { return x - floorf(x); }
 TOPO_HD float sat(float x) { return x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x); }
@@ -130,7 +194,7 @@ TOPO_HD void mat4_point(const float* m, float x, float y, float z, float* o) {
     }
 }
 
-TOPO_HD float linear_depth(float d) { return kFar * kNear / (kFar - d * (kFar - kNear)); }
+TOPO_HD float linear_depth(float d) { return div_f(kFar * kNear, kFar - d * (kFar - kNear)); }   // divisor in [50, 5e5] for d in [0, 1]
 
 // ---- sRGB ----------------------------------------------------------------------------------------
 // `thresh` points at 256 floats (TOPO_SRGB_THRESH_BITS reinterpreted; entry 255 = +inf), `decode` at 256.
@@ -193,7 +257,7 @@ TOPO_HD void shade_fragment(int view_mode, f3 sun, float cam_x, float cam_y, flo
     for (int k = 0; k < 3; ++k) {
         const float h1 = k == 0 ? hash12n(px, py) : hash12n(px + off[k], py + off[k]);
         const float h2 = k == 0 ? hash12n(qx, qy) : hash12n(qx + off[k], qy + off[k]);
-        out[k] = lin + 1.0f * (h1 + h2 - 1.0f) / 255.0f;
+        out[k] = lin + div_const(1.0f * (h1 + h2 - 1.0f), 255.0f, 1.0f / 255.0f);
     }
 }
 
@@ -206,7 +270,7 @@ TOPO_HD uint32_t post_pixel(const float* thresh, const float* decode, uint32_t c
     float contour = 8.0f * center;
 #pragma unroll
     for (int k = 0; k < 8; ++k) contour -= ln[k];
-    float t = sat((contour / center - 0.05f) / (0.15f - 0.05f));
+    float t = sat(div_const(div_f(contour, center) - 0.05f, 0.15f - 0.05f, 1.0f / (0.15f - 0.05f)));   // center in [50, 5e5]
     const float a = t * t * (3.0f - 2.0f * t);
     // mix(x, 0, 0) = x*1 + 0*0 = x and the decode->encode round trip of a code is the identity (checked when the
     // tables are generated), alpha stays 255; mix(x, 0, 1) = x*0 + 0*1 = 0: both ends skip the table work.

@@ -15,6 +15,8 @@ struct TileDev {                 // one loaded 1x1 degree tile (RenderBuffer, re
     const float* heights;        // w*h f32, row-major, row 0 = north      (R32Float texture)
     uint32_t* normals;           // w*h packed rgba8unorm, zero-initialised (Rgba8Unorm texture)
     const float* block_minmax;   // 2 floats per raster block: min, max height of its vertices
+    const float* trig_lon;       // w (sin, cos) pairs: sincos_f(vertex_lon(t, x)) of every vertex column ...
+    const float* trig_lat;       // h pairs: sincos_f(vertex_lat(t, y)) of every vertex row (load phase, k_block_minmax)
     float raster_x, raster_y;    // TerrainUniforms (render/data.rs:113-121)
     float model_x, model_y;
     float scale_x, scale_y;
@@ -63,10 +65,13 @@ TOPO_HD f3 vertex_world(const TileDev& t, uint32_t vx, uint32_t vy, float height
     return world_from_sincos(height, sla, cla, slo, clo);
 }
 
-TOPO_HD f3 vertex_normal(const TileDev& t, uint32_t packed) {
-    const float nx = 2.0f * from_unorm8(packed & 255u) - 1.0f;
-    const float ny = 2.0f * from_unorm8((packed >> 8) & 255u) - 1.0f;
-    const float nz = 2.0f * from_unorm8((packed >> 16) & 255u) - 1.0f;
+// 2 * (c / 255) - 1: the shader's decode of one normal channel.  `ndec`, when given, is that function tabulated for
+// c = 0..255 (k_resolve keeps it in LDS: one lookup instead of six instructions per channel).
+TOPO_HD float normal_channel(uint32_t c) { return 2.0f * from_unorm8(c) - 1.0f; }
+TOPO_HD f3 vertex_normal(const TileDev& t, uint32_t packed, const float* ndec = nullptr) {
+    const float nx = ndec ? ndec[packed & 255u] : normal_channel(packed & 255u);
+    const float ny = ndec ? ndec[(packed >> 8) & 255u] : normal_channel((packed >> 8) & 255u);
+    const float nz = ndec ? ndec[(packed >> 16) & 255u] : normal_channel((packed >> 16) & 255u);
     const float* m = t.rot;   // mat * vec4(n, 0): fma chain, the zero w column drops out
     return {fmaf(m[6], nz, fmaf(m[3], ny, m[0] * nx)), fmaf(m[7], nz, fmaf(m[4], ny, m[1] * nx)),
             fmaf(m[8], nz, fmaf(m[5], ny, m[2] * nx))};
@@ -81,7 +86,7 @@ TOPO_HD int clip_to_screen(const float clip[4], float W, float H, SVert& s) {
         s.flag = kVtxNear;
         return kVtxNear;
     }
-    const float iw = 1.0f / clip[3];                 // perspective divide = one reciprocal + multiplies
+    const float iw = div_f(1.0f, clip[3]);           // perspective divide = one reciprocal + multiplies (w >= near here)
     const float nx = clip[0] * iw, ny = clip[1] * iw, nz = clip[2] * iw;
     const float hw = 0.5f * W, hh = 0.5f * H;       // exact: W, H are small integers
     const float xf = fmaf(nx, hw, hw);              // 0.5*(ndc.x + 1)*W
@@ -159,7 +164,7 @@ TOPO_HD bool triangle_setup(const SVert& s0, const SVert& s1, const SVert& s2, i
         const bool own = (ts.dy[e] > 0) || (ts.dy[e] == 0 && ts.dx[e] < 0);
         ts.bias[e] = own ? 0 : -1;
     }
-    ts.iA = 1.0f / (float)(-area2);
+    ts.iA = div_f(1.0f, (float)(-area2));
     ts.z0 = s0.z; ts.dz1 = s1.z - s0.z; ts.dz2 = s2.z - s0.z;
     return true;
 }
@@ -202,14 +207,14 @@ TOPO_HD bool triangle_bary(const SVert& s0, const SVert& s1, const SVert& s2, in
     if ((mxx - mnx) < (1 << 14) && (mxy - mny) < (1 << 14)) {
         const int32_t area2 = TOPO_MUL24(X1 - X0, Y2 - Y0) - TOPO_MUL24(Y1 - Y0, X2 - X0);
         if (area2 >= 0) return false;
-        const float iA = 1.0f / (float)(-area2);
+        const float iA = div_f(1.0f, (float)(-area2));
         b[0] = (float)(TOPO_MUL24(Y2 - Y1, cx - X1) - TOPO_MUL24(X2 - X1, cy - Y1)) * iA;
         b[1] = (float)(TOPO_MUL24(Y0 - Y2, cx - X2) - TOPO_MUL24(X0 - X2, cy - Y2)) * iA;
         b[2] = (float)(TOPO_MUL24(Y1 - Y0, cx - X0) - TOPO_MUL24(X1 - X0, cy - Y0)) * iA;
     } else {
         const int64_t area2 = (int64_t)(X1 - X0) * (Y2 - Y0) - (int64_t)(Y1 - Y0) * (X2 - X0);
         if (area2 >= 0) return false;
-        const float iA = 1.0f / (float)(-area2);
+        const float iA = div_f(1.0f, (float)(-area2));
         b[0] = (float)((int64_t)(Y2 - Y1) * (cx - X1) - (int64_t)(X2 - X1) * (cy - Y1)) * iA;
         b[1] = (float)((int64_t)(Y0 - Y2) * (cx - X2) - (int64_t)(X0 - X2) * (cy - Y2)) * iA;
         b[2] = (float)((int64_t)(Y1 - Y0) * (cx - X0) - (int64_t)(X1 - X0) * (cy - Y0)) * iA;
@@ -236,7 +241,7 @@ TOPO_HD VFull lerp_vertex(const VFull& I, const VFull& O, float t) {
 }
 
 TOPO_HD VFull clip_edge(const VFull& I, const VFull& O) {   // I inside (z_clip >= 0), O outside
-    return lerp_vertex(I, O, I.clip[2] / (I.clip[2] - O.clip[2]));
+    return lerp_vertex(I, O, div_f(I.clip[2], I.clip[2] - O.clip[2]));
 }
 
 // Triangle number `fan` (0 or 1) of the clipped polygon, written out case by case so that nothing is indexed at
@@ -285,8 +290,8 @@ TOPO_HD bool clip_near_fan(const VFull& v0, const VFull& v1, const VFull& v2, ui
 // ---- perspective-correct varyings --------------------------------------------------------------------
 TOPO_HD void interpolate(const VFull& v0, const VFull& v1, const VFull& v2, const float b[3], f3& wpos, f3& wnrm) {
     // q_i = b_i * (1/w_i); a = (a0*q0 + a1*q1 + a2*q2) * (1 / (q0+q1+q2)), sums as fma chains
-    const float q0 = b[0] * (1.0f / v0.clip[3]), q1 = b[1] * (1.0f / v1.clip[3]), q2 = b[2] * (1.0f / v2.clip[3]);
-    const float iq = 1.0f / ((q0 + q1) + q2);
+    const float q0 = b[0] * div_f(1.0f, v0.clip[3]), q1 = b[1] * div_f(1.0f, v1.clip[3]), q2 = b[2] * div_f(1.0f, v2.clip[3]);
+    const float iq = div_f(1.0f, (q0 + q1) + q2);
     wpos.x = fmaf(v2.wpos.x, q2, fmaf(v1.wpos.x, q1, v0.wpos.x * q0)) * iq;
     wpos.y = fmaf(v2.wpos.y, q2, fmaf(v1.wpos.y, q1, v0.wpos.y * q0)) * iq;
     wpos.z = fmaf(v2.wpos.z, q2, fmaf(v1.wpos.z, q1, v0.wpos.z * q0)) * iq;
@@ -308,18 +313,17 @@ struct ResolvedTri {
     SVert s[3];
     TriSetup ts;
 };
-TOPO_HD bool resolve_vertices(const TileDev& t, uint32_t tile_w, uint32_t tile_h, const ViewDev& view, int32_t W, int32_t H,
-                              uint32_t tri, uint32_t fan, ResolvedTri& r) {
+TOPO_HD bool resolve_vertices(const TileDev& t, uint32_t tile_w, FastDiv div_hm1, uint32_t hm1, const ViewDev& view, int32_t W, int32_t H,
+                              uint32_t tri, uint32_t fan, const float* ndec, ResolvedTri& r) {
     // the triangle's three vertices are corners of one grid cell: two distinct longitudes, two distinct latitudes,
-    // so four sin/cos pairs serve all three vertices (same function of the same input as vertex_world)
-    const uint32_t cell = tri >> 1, k = tri & 1u, hm1 = tile_h - 1;
-    const uint32_t ci = cell / hm1, cj = cell - ci * hm1;
+    // whose sin/cos pairs come from the tile's tables (same function of the same input as vertex_world)
+    const uint32_t cell = tri >> 1, k = tri & 1u;
+    const uint32_t ci = fastdiv(cell, div_hm1), cj = cell - ci * hm1;
     const bool even = ((ci + cj) & 1u) == 0;
-    float slo0, clo0, slo1, clo1, sla0, cla0, sla1, cla1;
-    sincos_f(vertex_lon(t, ci), slo0, clo0);
-    sincos_f(vertex_lon(t, ci + 1), slo1, clo1);
-    sincos_f(vertex_lat(t, cj), sla0, cla0);
-    sincos_f(vertex_lat(t, cj + 1), sla1, cla1);
+    const auto tlon = TOPO_GLOBAL_F32(t.trig_lon) + 2 * ci;
+    const auto tlat = TOPO_GLOBAL_F32(t.trig_lat) + 2 * cj;
+    const float slo0 = tlon[0], clo0 = tlon[1], slo1 = tlon[2], clo1 = tlon[3];
+    const float sla0 = tlat[0], cla0 = tlat[1], sla1 = tlat[2], cla1 = tlat[3];
     // corner offsets (render_buffer.rs:191-219): k=0: a, b, (even ? d : c);  k=1: d, c, (even ? a : b)
     const uint32_t ox[3] = {k, k, 1u - k};
     const uint32_t oy[3] = {k, 1u - k, k == 0 ? (even ? 1u : 0u) : (even ? 0u : 1u)};
@@ -328,7 +332,7 @@ TOPO_HD bool resolve_vertices(const TileDev& t, uint32_t tile_w, uint32_t tile_h
         const size_t idx = (size_t)(cj + oy[q]) * tile_w + (ci + ox[q]);
         r.v[q].wpos = world_from_sincos(TOPO_GLOBAL_F32(t.heights)[idx], oy[q] ? sla1 : sla0, oy[q] ? cla1 : cla0, ox[q] ? slo1 : slo0,
                                         ox[q] ? clo1 : clo0);
-        r.v[q].wnrm = vertex_normal(t, TOPO_GLOBAL_U32(t.normals)[idx]);
+        r.v[q].wnrm = vertex_normal(t, TOPO_GLOBAL_U32(t.normals)[idx], ndec);
         mat4_point(view.proj, r.v[q].wpos.x, r.v[q].wpos.y, r.v[q].wpos.z, r.v[q].clip);
     }
     const bool all_in = r.v[0].clip[2] >= 0.0f && r.v[1].clip[2] >= 0.0f && r.v[2].clip[2] >= 0.0f;
@@ -345,9 +349,9 @@ TOPO_HD bool resolve_vertices(const TileDev& t, uint32_t tile_w, uint32_t tile_h
     return true;
 }
 
-TOPO_HD bool resolve_triangle(const TileDev& t, uint32_t tile_w, uint32_t tile_h, const ViewDev& view, int32_t W,
+TOPO_HD bool resolve_triangle(const TileDev& t, uint32_t tile_w, FastDiv div_hm1, uint32_t hm1, const ViewDev& view, int32_t W,
                               int32_t H, uint32_t tri, uint32_t fan, ResolvedTri& r) {
-    return resolve_vertices(t, tile_w, tile_h, view, W, H, tri, fan, r) && triangle_setup(r.s[0], r.s[1], r.s[2], W, H, r.ts);
+    return resolve_vertices(t, tile_w, div_hm1, hm1, view, W, H, tri, fan, nullptr, r) && triangle_setup(r.s[0], r.s[1], r.s[2], W, H, r.ts);
 }
 
 // ---- peak visibility (render_engine.rs:338-396; glam Mat4::project_point3 + camera.rs:12-14) ---------------
