@@ -509,8 +509,13 @@ int TerrainRenderer::get_counters(uint32_t out[6]) {
     if (!d_counters_) return TOPO_OK;
     if (int rc = bind_device()) return rc;
     TOPO_HIP_TRY(hipStreamSynchronize(stream_));
-    uint32_t c[8];
+    uint32_t c[16];
     TOPO_HIP_TRY(hipMemcpy(c, d_counters_, sizeof c, hipMemcpyDeviceToHost));
+    if (getenv("TOPO_DEBUG_COUNTERS")) {   // raw queue counters, for kernel experiments
+        fprintf(stderr, "[topo] counters:");
+        for (int i = 0; i < 16; ++i) fprintf(stderr, " %u", c[i]);
+        fprintf(stderr, "\n");
+    }
     out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3]; out[4] = c[4]; out[5] = c[5];
     return TOPO_OK;
 }
