@@ -10,6 +10,8 @@ for grp in "$@"; do
   rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $R/gpurun_out/pmc_$TAG/$n -o p -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc_${TAG}_$n.log 2>&1
   n=$((n+1))
 done
+python3 $R/tools/summarize_pmc.py $R/gpurun_out/pmc_$TAG
+exit 0
 python3 - <<PY
 import csv,glob,collections
 acc=collections.defaultdict(lambda: collections.defaultdict(list))

@@ -716,12 +716,9 @@ __device__ __forceinline__ float unif(float v) { return __uint_as_float((uint32_
 // Up to four candidate fragments of one lane.  key == kVisClear marks "no fragment" (no real key equals it: ids
 // are < 0xFFFFFFFF and depths < 1.0).  With kPretest the current keys are read first, all four loads in flight
 // together, and only improving fragments issue an atomic; without it the atomics are issued blind (see vis_min:
-// the pre-test measured slower for both classes of triangle and is kept only as a build-time knob).
+// the pre-test measured slower and is kept only as a build-time knob).
 #ifndef TOPO_BIG_PRETEST_SMALL
 #define TOPO_BIG_PRETEST_SMALL false
-#endif
-#ifndef TOPO_BIG_PRETEST_GIANT
-#define TOPO_BIG_PRETEST_GIANT false
 #endif
 template <bool kPretest>
 __device__ __forceinline__ void vis_min4(uint64_t* __restrict__ vis, const uint32_t pix[4], const uint64_t key[4]) {
@@ -821,6 +818,9 @@ __global__ __launch_bounds__(256) void k_raster_big(FrameParams P) {
             }
             continue;
         }
+        // Giants (a vertex pair >= 64 px apart): the 64-bit edge functions of triangle_setup, evaluated once per lane at
+        // its pixel of the first 8x8 sub-chunk and then stepped (8 px in x: + 2048 dy, 8 px in y: - 2048 dx), so a
+        // sub-chunk costs three 64-bit additions instead of six 64-bit multiplications.
         SVert s[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) { s[k].X = bi.X[k]; s[k].Y = bi.Y[k]; s[k].z = bi.z[k]; s[k].flag = kVtxOk; }
@@ -828,23 +828,44 @@ __global__ __launch_bounds__(256) void k_raster_big(FrameParams P) {
         if (!triangle_setup(s[0], s[1], s[2], P.W, P.H, ts)) continue;
         const int32_t bx0 = max(ts.px0, rx * 64), bx1 = min(ts.px1, rx * 64 + 63);
         const int32_t by0 = max(ts.py0, ry * 64), by1 = min(ts.py1, ry * 64 + 63);
-        for (int32_t sy = by0 & ~7; sy <= by1; sy += 8)
-            for (int32_t sx = bx0 & ~7; sx <= bx1; sx += 32) {
-                uint32_t pix[4];
-                uint64_t key[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int32_t px = sx + 8 * k + lx, py = sy + ly;
-                    key[k] = kVisClear;
-                    pix[k] = 0;
-                    if (px < bx0 || px > bx1 || py < by0 || py > by1) continue;
-                    float z, b[3];
-                    if (!triangle_pixel(ts, px, py, z, b)) continue;
-                    pix[k] = (uint32_t)(py * P.W + px);
-                    key[k] = vis_key(z, bi.id);
+        if (bx0 > bx1 || by0 > by1) continue;
+        const int32_t sx0 = bx0 & ~7, sy0 = by0 & ~7;
+        const int64_t cx = (int64_t)(sx0 + lx) * 256 + 128, cy = (int64_t)(sy0 + ly) * 256 + 128;
+        int64_t Fr0 = ts.dy[0] * (cx - ts.ax[0]) - ts.dx[0] * (cy - ts.ay[0]) + ts.bias[0];   // biased: covered <=> all >= 0
+        int64_t Fr1 = ts.dy[1] * (cx - ts.ax[1]) - ts.dx[1] * (cy - ts.ay[1]) + ts.bias[1];
+        int64_t Fr2 = ts.dy[2] * (cx - ts.ax[2]) - ts.dx[2] * (cy - ts.ay[2]) + ts.bias[2];
+        const int64_t ax0 = ts.dy[0] * 2048, ax1 = ts.dy[1] * 2048, ax2 = ts.dy[2] * 2048;
+        const int64_t ay0 = ts.dx[0] * 2048, ay1 = ts.dx[1] * 2048, ay2 = ts.dx[2] * 2048;
+        // barycentric numerators of covered pixels are in [0, |area2|]: below 2^48 (any triangle under ~46000 px
+        // across) the int64 -> f32 conversion is one fma of two exact 24-bit halves, the same single rounding
+        const bool narrow = -((X1 - (int64_t)X0) * (Y2 - (int64_t)Y0) - (Y1 - (int64_t)Y0) * (X2 - (int64_t)X0)) < (1ll << 48);
+        const int32_t b1 = (int32_t)ts.bias[1], b2 = (int32_t)ts.bias[2];
+        for (int32_t sy = sy0; sy <= by1; sy += 8) {
+            int64_t F0 = Fr0, F1 = Fr1, F2 = Fr2;
+            const int32_t py = sy + ly;
+            const bool rowin = py >= by0 && py <= by1;
+            for (int32_t sx = sx0; sx <= bx1; sx += 8) {
+                const int32_t px = sx + lx;
+                if (rowin && px >= bx0 && px <= bx1 && (F0 | F1 | F2) >= 0) {
+                    const int64_t U1 = F1 - b1, U2 = F2 - b2;
+                    float f1, f2;
+                    if (narrow) {
+                        f1 = fmaf((float)(int32_t)(U1 >> 24), 16777216.0f, (float)(int32_t)((uint32_t)U1 & 0xFFFFFFu));
+                        f2 = fmaf((float)(int32_t)(U2 >> 24), 16777216.0f, (float)(int32_t)((uint32_t)U2 & 0xFFFFFFu));
+                    } else {
+                        f1 = (float)U1;
+                        f2 = (float)U2;
+                    }
+                    float z = fmaf(f1 * ts.iA, ts.dz1, fmaf(f2 * ts.iA, ts.dz2, ts.z0));
+                    if (z < 1.0f) {
+                        if (z < 0.0f) z = 0.0f;
+                        vis_min(vis + (size_t)py * P.W + px, vis_key(z, bi.id));
+                    }
                 }
-                vis_min4<TOPO_BIG_PRETEST_GIANT>(vis, pix, key);
+                F0 += ax0; F1 += ax1; F2 += ax2;
             }
+            Fr0 -= ay0; Fr1 -= ay1; Fr2 -= ay2;
+        }
     }
 }
 
