@@ -170,6 +170,26 @@ float topo_dist_from_depth(float depth);
 /* pad_256                                                                   data/mod.rs:9-11 */
 uint32_t topo_pad_256(uint32_t size);
 
+/* CoordinateTransform::from_geo_tag_data(pixel_scale, tie_points, model_transformation)   common/coordinate_transform.rs:23-57
+ * GeoTIFF ModelPixelScaleTag (3 doubles) + ModelTiepointTag (6 doubles) -> the six f32 the render path consumes.  A null
+ * pointer stands for an absent tag (None).  Returns TOPO_ERR_UNSUPPORTED for the reference's IncorrectGeoTags (a
+ * ModelTransformationTag is present, or one of the two required tags is absent) and TOPO_ERR_INVALID for
+ * IncorrectGeoTagData (wrong value counts). */
+int topo_coordinate_transform(const double* pixel_scale, uint32_t n_pixel_scale, const double* tie_points, uint32_t n_tie_points,
+                              const double* model_transformation, float raster_point[2], float model_point[2],
+                              float pixel_scale_out[2]);
+/* CoordinateTransform::to_model / to_raster                                  common/coordinate_transform.rs:59-71 */
+void topo_to_model(const float raster_point[2], const float model_point[2], const float pixel_scale[2], float x, float y,
+                   float out[2]);
+void topo_to_raster(const float raster_point[2], const float model_point[2], const float pixel_scale[2], float lon, float lat,
+                    float out[2]);
+/* get_height_value_at (F32 tiles)                                            common/coordinate_transform.rs:73-90
+ * The terrain height under (longitude, latitude), as the reference looks it up to place the camera
+ * (render_engine.rs:322-328): index = (raster.y as usize) * w + (raster.x as usize) with Rust's saturating float
+ * casts, no bounds check other than the slice's.  Returns TOPO_ERR_NOT_FOUND where the reference yields None. */
+int topo_height_value_at(const float* heights, uint32_t w, uint32_t h, const float raster_point[2], const float model_point[2],
+                         const float pixel_scale[2], double longitude, double latitude, float* out);
+
 /* UiController::get_locations_range(location, range_dist)                    control/ui_controller.rs:61-83
  * (the tile working set around a viewpoint; the reference calls it with 100 000 m).  Writes up
  * to `cap` (lat_deg, lon_deg) pairs in the reference's order -- sorted by (|lat - c_lat|, |lon - c_lon|), stable over

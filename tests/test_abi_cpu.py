@@ -121,3 +121,47 @@ def test_locations_range_matches_oracle_and_known_answer(topo, orc):
         rd = float(rng.choice([1.0e4, 1.0e5, 2.5e5]))
         assert topo.locations_range(la, lo, rd) == orc.locations_range(la, lo, rd), (la, lo, rd)
     assert topo.locations_range(0.2, 179.8)[0][1] in range(-180, 180)                         # wraps across the antimeridian
+
+
+def test_coordinate_transform_from_geo_tags(topo):
+    """CoordinateTransform::from_geo_tag_data (coordinate_transform.rs:23-57): values, f64 -> f32 narrowing, both errors."""
+    ps = [1.0 / 1200.0, 1.0 / 1200.0, 0.0]
+    tp = [0.0, 0.0, 0.0, 10.0 - 0.5 / 1200.0, 47.0 + 0.5 / 1200.0, 0.0]
+    ct = topo.CoordinateTransform.from_geo_tag_data(ps, tp)
+    assert ct.raster_point.tolist() == [0.0, 0.0]
+    assert ct.model_point.tolist() == [float(np.float32(tp[3])), float(np.float32(tp[4]))]
+    assert ct.pixel_scale.tolist() == [float(np.float32(ps[0]))] * 2
+    with pytest.raises(topo.TopoError) as e:          # ModelTransformationTag present -> IncorrectGeoTags
+        topo.CoordinateTransform.from_geo_tag_data(ps, tp, [1.0] * 16)
+    assert e.value.code == -2
+    for a, b in ((None, tp), (ps, None)):             # a required tag absent -> IncorrectGeoTags
+        with pytest.raises(topo.TopoError) as e:
+            topo.CoordinateTransform.from_geo_tag_data(a, b)
+        assert e.value.code == -2
+    for a, b in ((ps[:2], tp), (ps, tp[:5]), (ps + [0.0], tp)):   # wrong counts -> IncorrectGeoTagData
+        with pytest.raises(topo.TopoError) as e:
+            topo.CoordinateTransform.from_geo_tag_data(a, b)
+        assert e.value.code == -1
+
+
+def test_to_model_to_raster_and_height_lookup(topo):
+    """to_model / to_raster / get_height_value_at (coordinate_transform.rs:59-90) against the same f32 expressions in numpy."""
+    f = np.float32
+    ct = topo.CoordinateTransform([0.5, 0.5], [10.0, 48.0], [1.0 / 1200.0, 1.0 / 1200.0])
+    rp, mp, sc = ct.raster_point, ct.model_point, ct.pixel_scale
+    for x, y in ((0.0, 0.0), (600.0, 37.5), (1199.0, 1199.0)):
+        mx, my = ct.to_model(x, y)
+        assert f(mx) == (f(x) - rp[0]) * sc[0] + mp[0] and f(my) == (f(y) - rp[1]) * -sc[1] + mp[1]
+    w, h = 40, 30
+    hts = np.arange(w * h, dtype=np.float32).reshape(h, w)
+    ct = topo.CoordinateTransform([0.0, 0.0], [10.0, 48.0], [1.0 / w, 1.0 / h])
+    rng = np.random.default_rng(5)
+    for lon, lat in zip(rng.uniform(9.9, 11.1, 300), rng.uniform(46.9, 48.1, 300)):
+        rx = (f(lon) - ct.model_point[0]) / ct.pixel_scale[0] + ct.raster_point[0]
+        ry = (f(lat) - ct.model_point[1]) / -ct.pixel_scale[1] + ct.raster_point[1]
+        assert ct.to_raster(lon, lat) == (float(rx), float(ry))
+        ix, iy = (int(rx) if rx > 0 else 0), (int(ry) if ry > 0 else 0)     # Rust `as usize` saturates below at 0
+        idx = iy * w + ix                                                     # no per-axis bounds check in the reference
+        want = float(hts.reshape(-1)[idx]) if idx < w * h else None
+        assert ct.height_value_at(hts, lon, lat) == want
+    assert ct.height_value_at(hts, float("nan"), 47.5) == float(hts[int((f(47.5) - f(48.0)) / -ct.pixel_scale[1]), 0])

@@ -105,6 +105,10 @@ def lib():
             "topo_pad_256": (u32, [u32]),
             "topo_synth_tile": (None, [i32, i32, u32, u32, u32, vp]),
             "topo_locations_range": (u32, [f32, f32, f32, vp, u32]),
+            "topo_coordinate_transform": (C.c_int, [vp, u32, vp, u32, vp, vp, vp, vp]),
+            "topo_to_model": (None, [vp, vp, vp, f32, f32, vp]),
+            "topo_to_raster": (None, [vp, vp, vp, f32, f32, vp]),
+            "topo_height_value_at": (C.c_int, [vp, u32, u32, vp, vp, vp, C.c_double, C.c_double, vp]),
         }
         for name, (res, args) in sigs.items():
             fn = getattr(L, name)
@@ -162,6 +166,47 @@ def locations_range(latitude: float, longitude: float, range_dist: float = 100_0
     buf = np.zeros((4096, 2), np.int32)
     n = int(lib().topo_locations_range(latitude, longitude, range_dist, _p(buf), 4096))
     return [(int(a), int(b)) for a, b in buf[:min(n, 4096)]]
+
+
+class CoordinateTransform:
+    """CoordinateTransform (common/coordinate_transform.rs:16-71): the six f32 a tile's GeoTIFF tags reduce to."""
+
+    def __init__(self, raster_point, model_point, pixel_scale):
+        self.raster_point = np.asarray(raster_point, np.float32)
+        self.model_point = np.asarray(model_point, np.float32)
+        self.pixel_scale = np.asarray(pixel_scale, np.float32)
+
+    @classmethod
+    def from_geo_tag_data(cls, pixel_scale_data, tie_points_data, model_transformation_data=None):
+        """Raises TopoError(UNSUPPORTED) for IncorrectGeoTags and TopoError(INVALID) for IncorrectGeoTagData."""
+        arr = lambda v: None if v is None else np.ascontiguousarray(v, dtype=np.float64)
+        ps, tp, mt = arr(pixel_scale_data), arr(tie_points_data), arr(model_transformation_data)
+        rp, mp, sc = (np.zeros(2, np.float32) for _ in range(3))
+        ptr = lambda a: None if a is None else _p(a)
+        rc = lib().topo_coordinate_transform(ptr(ps), 0 if ps is None else ps.size, ptr(tp), 0 if tp is None else tp.size, ptr(mt),
+                                             _p(rp), _p(mp), _p(sc))
+        if rc != 0:
+            raise TopoError(rc, "IncorrectGeoTags" if rc == -2 else "IncorrectGeoTagData")
+        return cls(rp, mp, sc)
+
+    def to_model(self, x, y):
+        out = np.zeros(2, np.float32)
+        lib().topo_to_model(_p(self.raster_point), _p(self.model_point), _p(self.pixel_scale), x, y, _p(out))
+        return float(out[0]), float(out[1])
+
+    def to_raster(self, lon, lat):
+        out = np.zeros(2, np.float32)
+        lib().topo_to_raster(_p(self.raster_point), _p(self.model_point), _p(self.pixel_scale), lon, lat, _p(out))
+        return float(out[0]), float(out[1])
+
+    def height_value_at(self, heights: np.ndarray, longitude: float, latitude: float):
+        """get_height_value_at (coordinate_transform.rs:73-90): the f32 height, or None where the reference yields None."""
+        hts = np.ascontiguousarray(heights, dtype=np.float32)
+        h, w = hts.shape
+        out = np.zeros(1, np.float32)
+        rc = lib().topo_height_value_at(_p(hts), w, h, _p(self.raster_point), _p(self.model_point), _p(self.pixel_scale),
+                                        float(longitude), float(latitude), _p(out))
+        return None if rc != 0 else float(out[0])
 
 
 def post_uniforms(width, height, pixelize_n=100.0) -> np.ndarray:

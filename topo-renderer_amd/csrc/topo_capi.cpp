@@ -1,4 +1,5 @@
 // topo_capi.cpp -- the extern "C" boundary (include/topo_hip.h) over topo::TerrainRenderer.
+#include <cstdint>
 #include <cstring>
 #include <new>
 #include <string>
@@ -186,6 +187,48 @@ void topo_geometry_transform(float h, float lon_deg, float lat_deg, float out[3]
 float topo_dist_from_depth(float depth) { return topo::kFar * topo::kNear / (topo::kFar - depth * (topo::kFar - topo::kNear)); }
 
 uint32_t topo_pad_256(uint32_t size) { return ((size - 1) / 256 + 1) * 256; }
+
+int topo_coordinate_transform(const double* pixel_scale, uint32_t n_pixel_scale, const double* tie_points, uint32_t n_tie_points,
+                              const double* model_transformation, float rp[2], float mp[2], float ps[2]) {
+    if (!rp || !mp || !ps) return TOPO_ERR_INVALID;
+    if (model_transformation) return TOPO_ERR_UNSUPPORTED;            // IncorrectGeoTags
+    if (!pixel_scale || !tie_points) return TOPO_ERR_UNSUPPORTED;     // IncorrectGeoTags
+    if (n_pixel_scale != 3 || n_tie_points != 6) return TOPO_ERR_INVALID;   // IncorrectGeoTagData
+    rp[0] = (float)tie_points[0]; rp[1] = (float)tie_points[1];
+    mp[0] = (float)tie_points[3]; mp[1] = (float)tie_points[4];
+    ps[0] = (float)pixel_scale[0]; ps[1] = (float)pixel_scale[1];
+    return TOPO_OK;
+}
+
+void topo_to_model(const float rp[2], const float mp[2], const float ps[2], float x, float y, float out[2]) {
+    out[0] = (x - rp[0]) * ps[0] + mp[0];
+    out[1] = (y - rp[1]) * -ps[1] + mp[1];
+}
+
+void topo_to_raster(const float rp[2], const float mp[2], const float ps[2], float lon, float lat, float out[2]) {
+    out[0] = (lon - mp[0]) / ps[0] + rp[0];
+    out[1] = (lat - mp[1]) / -ps[1] + rp[1];
+}
+
+namespace {
+size_t rust_f32_as_usize(float v) {   // `as usize`: NaN -> 0, saturating at both ends, truncation toward zero
+    if (!(v > 0.0f)) return 0;
+    if (v >= 18446744073709551616.0f) return SIZE_MAX;
+    return (size_t)v;
+}
+}  // namespace
+
+int topo_height_value_at(const float* heights, uint32_t w, uint32_t h, const float rp[2], const float mp[2], const float ps[2],
+                         double longitude, double latitude, float* out) {
+    if (!heights || !rp || !mp || !ps || !out) return TOPO_ERR_INVALID;
+    float r[2];
+    topo_to_raster(rp, mp, ps, (float)longitude, (float)latitude, r);
+    const size_t ry = rust_f32_as_usize(r[1]), rx = rust_f32_as_usize(r[0]);
+    const unsigned __int128 index = (unsigned __int128)ry * w + rx;   // usize arithmetic cannot overflow for any real tile
+    if (index >= (unsigned __int128)w * h) return TOPO_ERR_NOT_FOUND;
+    *out = heights[(size_t)index];
+    return TOPO_OK;
+}
 
 uint32_t topo_locations_range(float latitude, float longitude, float range_dist, int32_t* out, uint32_t cap) {
     return topo::locations_range(latitude, longitude, range_dist, out, cap);
