@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--check", action="store_true", help="verify sector 0 against the oracle (slow)")
     ap.add_argument("--occlusion-split", type=float, default=None, help="metres; 0 disables the two-phase occlusion filter")
+    ap.add_argument("--pitch", type=float, default=0.0, help="camera pitch in radians (reference: positive looks down)")
     ap.add_argument("--host-path", action="store_true", help="also time topo_render (host outputs, PCIe-inclusive)")
     args = ap.parse_args()
 
@@ -103,7 +104,7 @@ def main():
     r.synchronize()
     setup_s = time.time() - t0
     eye = T.geometry_transform(ground + 50.0, vlon, vlat)            # render_engine.rs:327
-    views = T.panorama_uniforms(eye, 0.0, SW, PH, vlon, vlat, args.view_mode)
+    views = T.panorama_uniforms(eye, 0.0, SW, PH, vlon, vlat, args.view_mode, pitch=args.pitch)
     if args.workload == "c5":
         return bench_batch(args, T, np, torch, dist, r, locs, deg, SW, PH, rank, world, setup_s)
 
@@ -224,6 +225,7 @@ def main():
         "load_GBps": round(8.0 * n_tiles * TILE * TILE / (load_ms / 1e3) / 1e9, 1) if load_ms > 0 else None,
         "hbm_read_roofline_frac_frame": round((4.0 * n_tiles * TILE * TILE / (ms_per_step / 1e3) / 1e9) / HBM_PEAK_GBPS, 5),
         "counters": counters,
+        "terrain_pixel_frac": round(float((depth < 1.0).float().mean().item()), 4),   # this rank's sectors
         "setup_s": round(setup_s, 1),
         "upload_s": round(upload_s, 2),
     }

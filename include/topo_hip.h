@@ -205,7 +205,7 @@ void topo_synth_tile(int32_t lat_deg, int32_t lon_deg, uint32_t w, uint32_t h, u
 int topo_probe_sincos(topo_ctx* ctx, const float* x, float* s, float* c, size_t n);
 
 /* GPU unit-test probe: the device forms of the spec's IEEE divisions over n host floats.  kind 0: x / y (general
- * form, operands inside 2^-96 .. 2^96); kind 1: x / 255; kind 2: x / (0.15f - 0.05f) (y ignored for 1 and 2). */
+ * form, operands inside 2^-96 .. 2^96); kind 1: x / 255; kind 2: x / (0.15f - 0.05f); kind 3: sqrt(x) (y ignored for 1..3). */
 int topo_probe_div(topo_ctx* ctx, int32_t kind, const float* x, const float* y, float* out, size_t n);
 
 #ifdef __cplusplus

@@ -30,6 +30,16 @@ static TileDev make_dev(const EmulTile& e) {
 
 uint32_t emul_fastdiv(uint32_t n, uint32_t d) { return fastdiv(n, fastdiv_make(d)); }
 void emul_markstein_div(const float* x, float C, float* out, size_t n) { for (size_t i = 0; i < n; ++i) out[i] = markstein_div(x[i], C, 1.0f / C); }
+void emul_srgb_encode_both(const float* x, uint8_t* by_probes, uint8_t* by_lut, size_t n) {
+    float thresh[258];
+    for (int i = 0; i < 256; ++i) thresh[i] = bits_f(TOPO_SRGB_THRESH_BITS[i]);
+    thresh[255] = thresh[256] = thresh[257] = NAN;   // as k_resolve pads its LDS copy
+    const uint8_t* lut = reinterpret_cast<const uint8_t*>(TOPO_SRGB_LUT12_WORDS);   // little-endian host
+    for (size_t i = 0; i < n; ++i) {
+        by_probes[i] = (uint8_t)srgb_encode(thresh, x[i]);
+        by_lut[i] = (uint8_t)srgb_encode_lut(thresh, lut, x[i]);
+    }
+}
 void emul_sincos(const float* x, float* s, float* c, size_t n) { for (size_t i = 0; i < n; ++i) sincos_f(x[i], s[i], c[i]); }
 
 void emul_normals_interior(const EmulTile* e, int W, int H) {

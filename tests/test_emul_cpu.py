@@ -53,6 +53,34 @@ def test_constant_division():
         assert np.array_equal(out.view(np.uint32), ref.view(np.uint32))
 
 
+def test_srgb_lut_encode_equals_probes():
+    """srgb_encode_lut (12-bit table + two probes) counts the same thresholds as the eight-probe search: every f32 in
+    [0, 1.01] at a stride coprime to the bin size, all 255 thresholds and their neighbours, the bin edges, and the
+    values outside the unit interval."""
+    import ctypes as C
+    L = emul.lib()
+    L.emul_srgb_encode_both.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    hi = int(np.float32(1.01).view(np.uint32))
+    bits = np.arange(0, hi, 37, dtype=np.uint32)
+    edges = (np.arange(0, 4097, dtype=np.float32) / np.float32(4096.0)).view(np.uint32)
+    edges = np.concatenate([edges, edges + 1, np.maximum(edges, 1) - 1])
+    special = np.array([0.0, -0.0, -1.0, 2.0, 1e30, np.inf, -np.inf, np.nan, 1.0, 0.99999994], np.float32).view(np.uint32)
+    x = np.concatenate([bits, edges, special]).view(np.float32)
+    a, b = np.empty(x.size, np.uint8), np.empty(x.size, np.uint8)
+    L.emul_srgb_encode_both(x.ctypes.data, a.ctypes.data, b.ctypes.data, x.size)
+    assert np.array_equal(a, b)
+    # around every threshold (the emulation's probe version defines them): find them by bisection of the codes
+    xs = np.sort(x[np.isfinite(x) & (x >= 0) & (x <= 1.01)])
+    L.emul_srgb_encode_both(xs.ctypes.data, a[:xs.size].ctypes.data, b[:xs.size].ctypes.data, xs.size)
+    steps = np.nonzero(np.diff(a[:xs.size].astype(np.int32)))[0]
+    assert steps.size == 255
+    near = np.concatenate([(xs[steps].view(np.uint32)[:, None] + np.arange(0, 40, dtype=np.uint32)[None, :]).reshape(-1)]).view(np.float32)
+    near = np.ascontiguousarray(near)
+    a2, b2 = np.empty(near.size, np.uint8), np.empty(near.size, np.uint8)
+    L.emul_srgb_encode_both(near.ctypes.data, a2.ctypes.data, b2.ctypes.data, near.size)
+    assert np.array_equal(a2, b2)
+
+
 def test_fastdiv_is_exact():
     import ctypes as C
     L = emul.lib()

@@ -47,6 +47,9 @@ def test_division_probe(topo):
     # same divisor shared by several numerators, the perspective and area reciprocals
     w = rng.uniform(50.0, 1.0e6, n).astype(np.float32)
     assert np.array_equal(r.probe_div(0, np.ones_like(w), w).view(np.uint32), (np.float32(1.0) / w).view(np.uint32))
+    # square root (normalize): the hardware estimate corrected to the IEEE result
+    sq = np.concatenate([rng.uniform(0.0, 4.0, n), np.exp2(rng.uniform(-20, 50, n)), [0.0, 1.0, 4.0, 2.0]]).astype(np.float32)
+    assert np.array_equal(r.probe_div(3, sq, sq).view(np.uint32), np.sqrt(sq).view(np.uint32))
     # constants: x / 255 (dither) and x / 0.1 (contour), any magnitude the path can produce
     xs = np.concatenate([rng.uniform(-2.0, 2.0, n), rng.uniform(-1e-6, 1e-6, 1000), [0.0, 1.0, -1.0, 2.0 ** -24]]).astype(np.float32)
     for kind, c in ((1, np.float32(255.0)), (2, np.float32(0.15) - np.float32(0.05))):

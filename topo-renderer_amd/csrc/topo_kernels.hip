@@ -870,67 +870,103 @@ __global__ __launch_bounds__(256) void k_raster_big(FrameParams P) {
 }
 
 // ---- resolve: fs_main for the winner of every pixel, then the post pass --------------------------------
-__device__ __forceinline__ float vis_depth(const uint64_t* vis, int32_t W, int32_t H, int32_t x, int32_t y) {
-    x = x < 0 ? 0 : (x > W - 1 ? W - 1 : x);   // clamp-to-edge depth sampler (texture.rs:113-117)
-    y = y < 0 ? 0 : (y > H - 1 ? H - 1 : y);
-    return bits_f((uint32_t)(vis[(size_t)y * W + x] >> 32));
-}
-
-__global__ __launch_bounds__(256) void k_resolve(FrameParams P, OutputParams O) {
-    __shared__ float s_thresh[256];
+// One workgroup shades a 64 x kResolveRows px block, wave w taking rows w, w + 4, ...  The block's visibility keys
+// (+ 1 px halo for the contour taps, clamp-to-edge) are read from memory exactly once, into LDS: linear depth with
+// halo, raw depth and triangle id for the block's own pixels.  A block that holds no terrain at all (about half of a
+// panorama is sky) is written out as constants without any per-pixel work: with every tap at depth 1 the contour
+// term is exactly 0 (8c - 8 times c in integers) and the post pass returns the cleared texel unchanged.
+#ifndef TOPO_RESOLVE_ROWS
+#define TOPO_RESOLVE_ROWS 16
+#endif
+#ifndef TOPO_RESOLVE_WGS
+#define TOPO_RESOLVE_WGS 6
+#endif
+constexpr int kResolveRows = TOPO_RESOLVE_ROWS;
+__global__ __launch_bounds__(256, TOPO_RESOLVE_WGS) void k_resolve(FrameParams P, OutputParams O) {
+    __shared__ float s_thresh[258];    // sRGB code boundaries; [255..257] = NaN: never <= anything (srgb_encode_lut probes up to 256)
     __shared__ float s_decode[256];
     __shared__ float s_ndec[256];      // normal channel decode 2c/255 - 1
-    __shared__ float s_lin[6][66];     // linear depth of the 64x4 pixel block + 1 px halo (clamp-to-edge)
-    s_thresh[threadIdx.x] = bits_f(TOPO_SRGB_THRESH_BITS[threadIdx.x]);
-    s_decode[threadIdx.x] = bits_f(TOPO_SRGB_DECODE_BITS[threadIdx.x]);
-    s_ndec[threadIdx.x] = normal_channel(threadIdx.x);
+    __shared__ uint32_t s_lut[1024];   // 4096 one-byte bins of srgb_encode_lut
+    __shared__ float s_lin[kResolveRows + 2][66];   // linear depth of the block + halo
+    __shared__ uint32_t s_raw[kResolveRows][64];    // depth bits of the block's pixels
+    __shared__ uint32_t s_id[kResolveRows][64];     // winner ids
+    __shared__ uint32_t s_any[4];                   // per wave: did its part of the block + halo hold terrain
     const uint32_t view_idx = blockIdx.z;
     const uint64_t* vis = P.vis + (size_t)view_idx * P.W * P.H;
-    const int32_t bx = blockIdx.x * 64, by = blockIdx.y * 4;
-    for (int idx = threadIdx.x; idx < 6 * 66; idx += 256) {
+    const int32_t bx = blockIdx.x * 64, by = blockIdx.y * kResolveRows;
+    bool terrain = false;
+    for (int idx = threadIdx.x; idx < (kResolveRows + 2) * 66; idx += 256) {
         const int ly = idx / 66, lx = idx - ly * 66;
-        s_lin[ly][lx] = linear_depth(vis_depth(vis, P.W, P.H, bx + lx - 1, by + ly - 1));
+        int32_t x = bx + lx - 1, y = by + ly - 1;
+        x = x < 0 ? 0 : (x > P.W - 1 ? P.W - 1 : x);   // clamp-to-edge depth sampler (texture.rs:113-117)
+        y = y < 0 ? 0 : (y > P.H - 1 ? P.H - 1 : y);
+        const uint64_t key = vis[(size_t)y * P.W + x];
+        const uint32_t hi = (uint32_t)(key >> 32);
+        terrain |= hi != 0x3F800000u;
+        s_lin[ly][lx] = linear_depth(bits_f(hi));
+        if (lx >= 1 && lx <= 64 && ly >= 1 && ly <= kResolveRows) {
+            s_raw[ly - 1][lx - 1] = hi;
+            s_id[ly - 1][lx - 1] = (uint32_t)key;
+        }
     }
+    const uint64_t any_mask = __ballot(terrain);
+    if ((threadIdx.x & 63) == 0) s_any[threadIdx.x >> 6] = any_mask != 0 ? 1u : 0u;
+    s_thresh[threadIdx.x] = threadIdx.x < 255 ? bits_f(TOPO_SRGB_THRESH_BITS[threadIdx.x]) : NAN;
+    if (threadIdx.x < 2) s_thresh[256 + threadIdx.x] = NAN;
+    s_decode[threadIdx.x] = bits_f(TOPO_SRGB_DECODE_BITS[threadIdx.x]);
+    s_ndec[threadIdx.x] = normal_channel(threadIdx.x);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s_lut[threadIdx.x + 256 * k] = TOPO_SRGB_LUT12_WORDS[threadIdx.x + 256 * k];
     __syncthreads();
-    const int32_t tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int32_t px = bx + tx, py = by + ty;
-    if (px >= P.W || py >= P.H) return;
-    const ViewDev& view = P.views[view_idx];
-    const uint64_t key = vis[(size_t)py * P.W + px];
-    const float depth = bits_f((uint32_t)(key >> 32));
-    const uint32_t id = (uint32_t)key;
-    // render target texel (Rgba8UnormSrgb): the cleared value or the shaded winner
-    uint32_t c8 = P.sky_c8;
-    if (id != kNoTri) {
-        float lin[4] = {0.0f, 0.71f, 0.885f, 1.0f};
-        const uint32_t draw = id >> 1, fan = id & 1u;
-        const uint32_t rank = fastdiv(draw, P.div_tris), tri = draw - rank * P.tris_per_tile;
-        ResolvedTri r;
-        float b[3];
-        if (resolve_vertices(P.tiles[rank], P.tile_w, P.div_hm1, P.tile_h - 1, view, P.W, P.H, tri, fan, s_ndec, r) &&
-            triangle_bary(r.s[0], r.s[1], r.s[2], px, py, b)) {
-            f3 wpos, wnrm;
-            interpolate(r.v[0], r.v[1], r.v[2], b, wpos, wnrm);
-            const f3 sun = {view.sun[0], view.sun[1], view.sun[2]};
-            shade_fragment(view.view_mode, sun, view.cam_x, view.cam_y, (float)px + 0.5f, (float)py + 0.5f, wpos, wnrm, lin);
+    const int32_t tx = threadIdx.x & 63, px = bx + tx;
+    if (px >= P.W) return;
+    uint8_t* const rgba_col = O.rgba + (size_t)view_idx * O.rgba_view_stride + (size_t)px * 4;
+    uint8_t* const depth_col = O.depth ? reinterpret_cast<uint8_t*>(O.depth) + (size_t)view_idx * O.depth_view_stride + (size_t)px * 4 : nullptr;
+    if ((s_any[0] | s_any[1] | s_any[2] | s_any[3]) == 0) {      // workgroup-uniform
+        for (int32_t ty = threadIdx.x >> 6; ty < kResolveRows && by + ty < P.H; ty += 4) {
+            *reinterpret_cast<uint32_t*>(rgba_col + (size_t)(by + ty) * O.rgba_pitch) = P.sky_c8;
+            if (depth_col) *reinterpret_cast<float*>(depth_col + (size_t)(by + ty) * O.depth_pitch) = 1.0f;
         }
-        c8 = srgb_encode(s_thresh, lin[0]) | (srgb_encode(s_thresh, lin[1]) << 8) | (srgb_encode(s_thresh, lin[2]) << 16) |
-             (to_unorm8(lin[3]) << 24);
+        return;
     }
-    float ln[8];
-    int k = 0;
-#pragma unroll
-    for (int i = -1; i <= 1; ++i)
-#pragma unroll
-        for (int j = -1; j <= 1; ++j) {
-            if (i == 0 && j == 0) continue;
-            ln[k++] = s_lin[ty + 1 + j][tx + 1 + i];
+    const uint8_t* lut = reinterpret_cast<const uint8_t*>(s_lut);
+    const ViewDev& view = P.views[view_idx];
+#pragma unroll 1
+    for (int32_t ty = threadIdx.x >> 6; ty < kResolveRows; ty += 4) {
+        const int32_t py = by + ty;
+        if (py >= P.H) break;
+        const uint32_t id = s_id[ty][tx];
+        // render target texel (Rgba8UnormSrgb): the cleared value or the shaded winner
+        uint32_t c8 = P.sky_c8;
+        if (id != kNoTri) {
+            float lin[4] = {0.0f, 0.71f, 0.885f, 1.0f};
+            const uint32_t draw = id >> 1, fan = id & 1u;
+            const uint32_t rank = fastdiv(draw, P.div_tris), tri = draw - rank * P.tris_per_tile;
+            ResolvedTri r;
+            float b[3];
+            if (resolve_vertices(P.tiles[rank], P.tile_w, P.div_hm1, P.tile_h - 1, view, P.W, P.H, tri, fan, s_ndec, r) &&
+                triangle_bary(r.s[0], r.s[1], r.s[2], px, py, b)) {
+                f3 wpos, wnrm;
+                interpolate(r.v[0], r.v[1], r.v[2], b, wpos, wnrm);
+                const f3 sun = {view.sun[0], view.sun[1], view.sun[2]};
+                shade_fragment(view.view_mode, sun, view.cam_x, view.cam_y, (float)px + 0.5f, (float)py + 0.5f, wpos, wnrm, lin);
+            }
+            c8 = srgb_encode_lut(s_thresh, lut, lin[0]) | (srgb_encode_lut(s_thresh, lut, lin[1]) << 8) |
+                 (srgb_encode_lut(s_thresh, lut, lin[2]) << 16) | (to_unorm8(lin[3]) << 24);
         }
-    const uint32_t out = post_pixel(s_thresh, s_decode, c8, s_lin[ty + 1][tx + 1], ln);
-    *reinterpret_cast<uint32_t*>(O.rgba + (size_t)view_idx * O.rgba_view_stride + (size_t)py * O.rgba_pitch + (size_t)px * 4) = out;
-    if (O.depth)
-        *reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(O.depth) + (size_t)view_idx * O.depth_view_stride +
-                                  (size_t)py * O.depth_pitch + (size_t)px * 4) = depth;
+        float ln[8];
+        int k = 0;
+#pragma unroll
+        for (int i = -1; i <= 1; ++i)
+#pragma unroll
+            for (int j = -1; j <= 1; ++j) {
+                if (i == 0 && j == 0) continue;
+                ln[k++] = s_lin[ty + 1 + j][tx + 1 + i];
+            }
+        const uint32_t out = post_pixel(s_thresh, s_decode, c8, s_lin[ty + 1][tx + 1], ln, lut);
+        *reinterpret_cast<uint32_t*>(rgba_col + (size_t)py * O.rgba_pitch) = out;
+        if (depth_col) *reinterpret_cast<uint32_t*>(depth_col + (size_t)py * O.depth_pitch) = s_raw[ty][tx];
+    }
 }
 
 // One lane per peak: project, one depth lookup, one comparison (render_engine.rs:338-396).
@@ -961,7 +997,10 @@ __global__ void k_probe_sincos(const float* x, float* s, float* c, size_t n) {
 __global__ void k_probe_div(int kind, const float* x, const float* y, float* out, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    out[i] = kind == 0 ? div_f(x[i], y[i]) : kind == 1 ? div_const(x[i], 255.0f, 1.0f / 255.0f) : div_const(x[i], 0.15f - 0.05f, 1.0f / (0.15f - 0.05f));
+    out[i] = kind == 0   ? div_f(x[i], y[i])
+             : kind == 1 ? div_const(x[i], 255.0f, 1.0f / 255.0f)
+             : kind == 2 ? div_const(x[i], 0.15f - 0.05f, 1.0f / (0.15f - 0.05f))
+                         : sqrt_f(x[i]);
 }
 
 }  // namespace
@@ -1050,7 +1089,7 @@ void launch_raster_big(const FrameParams& p, hipStream_t s) {
 }
 
 void launch_resolve(const FrameParams& p, const OutputParams& o, hipStream_t s) {
-    hipLaunchKernelGGL(k_resolve, dim3((p.W + 63) / 64, (p.H + 3) / 4, p.n_views), dim3(256), 0, s, p, o);
+    hipLaunchKernelGGL(k_resolve, dim3((p.W + 63) / 64, (p.H + kResolveRows - 1) / kResolveRows, p.n_views), dim3(256), 0, s, p, o);
 }
 
 void launch_visible_peaks(const float* proj16_dev, uint32_t w, uint32_t h, const float* depth, size_t depth_pitch, uint32_t n,

@@ -98,6 +98,20 @@ TOPO_HD float div_by(float x, Recip d) {
 #endif
 }
 TOPO_HD float div_f(float x, float y) { return div_by(x, recip_of(y)); }
+// sqrt(x), correctly rounded: the hardware estimate (1 ulp) moved to whichever neighbour the two residuals pick,
+// i.e. the compiler's own expansion of sqrtf without its input scaling (x is 0.01 .. 1e15 on this path).
+TOPO_HD float sqrt_f(float x) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(TOPO_EXP_OLD_SQRT)
+    float s = __builtin_amdgcn_sqrtf(x);
+    const float dn = __uint_as_float(__float_as_uint(s) - 1u), up = __uint_as_float(__float_as_uint(s) + 1u);
+    const float rdn = fmaf(-dn, s, x), rup = fmaf(-up, s, x);
+    s = rdn <= 0.0f ? dn : s;
+    return rup > 0.0f ? up : s;
+#else
+    return sqrtf(x);
+#endif
+}
+
 // x / C for a constant C whose correctly rounded reciprocal RC is known: one Markstein correction of x * RC.
 // Exhaustively checked against the IEEE quotient for C = 255 (every finite x) and C = 0.15f - 0.05f
 // (2^-97 <= |x| < 2^123 and 0), see tests/test_emul_cpu.py::test_constant_division.
@@ -165,7 +179,7 @@ TOPO_HD float cos_f(float x) {
 TOPO_HD float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 TOPO_HD f3 cross3(f3 a, f3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 TOPO_HD f3 normalize3(f3 a) {   // |a| is 0.3 .. 2 on this path (interpolated unit-ish normals, stencil cross products > 1 m^2)
-    const Recip len = recip_of(sqrtf(dot3(a, a)));
+    const Recip len = recip_of(sqrt_f(dot3(a, a)));
     return {div_by(a.x, len), div_by(a.y, len), div_by(a.z, len)};
 }
 TOPO_HD float fract_f(float x) { return x - floorf(x); }
@@ -209,6 +223,16 @@ TOPO_HD uint32_t srgb_encode(const float* thresh, float l) {
         if (thresh[lo + step - 1] <= l) lo += step;
     }
     return lo;
+}
+
+// The same count through a 12-bit first-level table: `lut` holds, for each bin [i/4096, (i+1)/4096), the number of
+// thresholds <= its left edge (TOPO_SRGB_LUT12_WORDS as bytes); at most two thresholds lie inside a bin, so two
+// probes finish the count.  `thresh` must be readable up to index 256 with entries 255.. = NaN (never <= anything).  Equal to
+// srgb_encode for every f32 input, NaN included (tests/test_emul_cpu.py::test_srgb_lut_encode_equals_probes).
+TOPO_HD uint32_t srgb_encode_lut(const float* thresh, const uint8_t* lut, float l) {
+    const uint32_t bin = (uint32_t)fminf(fmaxf(l * 4096.0f, 0.0f), 4095.0f);   // exact product; NaN and negatives -> bin 0
+    const uint32_t base = lut[bin];
+    return base + (thresh[base] <= l ? 1u : 0u) + (thresh[base + 1] <= l ? 1u : 0u);
 }
 
 // ---- normal stencil (compute_normals*.wgsl) ------------------------------------------------------
@@ -264,7 +288,9 @@ TOPO_HD void shade_fragment(int view_mode, f3 sun, float cam_x, float cam_y, flo
 // ---- post pass (postprocessing_shader.wgsl:68-96) -------------------------------------------------
 // `c8` = the render-target texel (sRGB8 rgb + unorm8 alpha); taps in the shader's loop order (i outer = x
 // offset -1..1, j inner = y offset -1..1, centre skipped).
-TOPO_HD uint32_t post_pixel(const float* thresh, const float* decode, uint32_t c8, float center, const float ln[8]) {
+// `lut` (may be null) selects srgb_encode_lut over srgb_encode: same result, fewer probes.
+TOPO_HD uint32_t post_pixel(const float* thresh, const float* decode, uint32_t c8, float center, const float ln[8],
+                            const uint8_t* lut = nullptr) {
     // center / ln[] are ALREADY linear_depth() of the depth taps (each is a pure function of its texel, so a
     // kernel may compute it once per texel and share it between the up to nine pixels that tap it).
     float contour = 8.0f * center;
@@ -280,6 +306,9 @@ TOPO_HD uint32_t post_pixel(const float* thresh, const float* decode, uint32_t c
     const float g = decode[(c8 >> 8) & 255u] * (1.0f - a) + 0.0f * a;
     const float b = decode[(c8 >> 16) & 255u] * (1.0f - a) + 0.0f * a;
     const float al = from_unorm8(c8 >> 24) * (1.0f - a) + 1.0f * a;
+    if (lut)
+        return srgb_encode_lut(thresh, lut, r) | (srgb_encode_lut(thresh, lut, g) << 8) | (srgb_encode_lut(thresh, lut, b) << 16) |
+               (to_unorm8(al) << 24);
     return srgb_encode(thresh, r) | (srgb_encode(thresh, g) << 8) | (srgb_encode(thresh, b) << 16) |
            (to_unorm8(al) << 24);
 }
