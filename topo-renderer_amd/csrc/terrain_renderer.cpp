@@ -67,7 +67,7 @@ TerrainRenderer::~TerrainRenderer() {
         (void)hipFree(kv.second.d_normals);
         (void)hipFree(kv.second.d_minmax);
     }
-    void* bufs[] = {d_tiles_, d_views_, d_vis_, d_work_, d_work2_, d_far_, d_big_, d_rare_, d_counters_, d_out_rgba_, d_out_depth_,
+    void* bufs[] = {d_tiles_, d_views_, d_vis_, d_dirty_, d_work_, d_work2_, d_far_, d_big_, d_rare_, d_counters_, d_out_rgba_, d_out_depth_,
                     d_edge_jobs_, d_corner_jobs_, d_peaks_, d_proj_};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
@@ -284,7 +284,14 @@ int TerrainRenderer::render_views_device(uint32_t n, const topo_uniforms* views,
     const size_t work_cap = (size_t)n * n_tiles * bxc * byc;
     const size_t big_cap = big_cap_cfg_ ? big_cap_cfg_ : (1u << 22), rare_cap = rare_cap_cfg_ ? rare_cap_cfg_ : (1u << 22);
     if (work_cap >= (1ull << 30)) return fail(TOPO_ERR_CAPACITY, "too many raster blocks in one submission");
-    if (int rc = ensure(&d_vis_, &cap_vis_, pixels * 8)) return rc;
+    if (pixels >= (1ull << 32)) return fail(TOPO_ERR_CAPACITY, "more than 2^32 pixels in one submission");
+    const size_t vis_keys = (pixels + 63) & ~(size_t)63;   // whole 64-key segments: k_clear rewrites segments, not keys
+    if (vis_keys * 8 > cap_vis_) {
+        // a fresh buffer holds garbage: mark every segment so that the first k_clear initialises all of it
+        if (int rc = ensure(&d_vis_, &cap_vis_, vis_keys * 8)) return rc;
+        if (int rc = ensure(&d_dirty_, &cap_dirty_, vis_keys / 64 + 64)) return rc;
+        TOPO_HIP_TRY(hipMemsetAsync(d_dirty_, 1, cap_dirty_, stream_));
+    }
     if (int rc = ensure(&d_views_, &cap_views_, sizeof(ViewDev) * kMaxViewsPerSlot * kViewSlots)) return rc;
     const size_t near_cap = 8 * work_cap;   // a near block is cut into strips of >= 2 cell rows: at most 8
     if (int rc = ensure(&d_work_, &cap_work_, (near_cap ? near_cap : 1) * sizeof(WorkItem))) return rc;
@@ -324,6 +331,7 @@ int TerrainRenderer::render_views_device(uint32_t n, const topo_uniforms* views,
     p.tiles = (const TileDev*)d_tiles_;
     p.views = d_slot;
     p.vis = (uint64_t*)d_vis_;
+    p.dirty = (uint8_t*)d_dirty_;
     p.work = (WorkItem*)d_work_;
     p.counters = (uint32_t*)d_counters_;
     p.big = (BigItem*)d_big_;

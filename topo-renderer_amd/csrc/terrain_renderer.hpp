@@ -98,6 +98,7 @@ class TerrainRenderer {
     void* d_tiles_ = nullptr;    size_t cap_tiles_ = 0;
     void* d_views_ = nullptr;    size_t cap_views_ = 0;
     void* d_vis_ = nullptr;      size_t cap_vis_ = 0;
+    void* d_dirty_ = nullptr;    size_t cap_dirty_ = 0;   // one mark per 64 visibility keys (topo_kernels.hip: struct Vis)
     void* d_work_ = nullptr;     size_t cap_work_ = 0;
     void* d_work2_ = nullptr;    size_t cap_work2_ = 0;
     void* d_far_ = nullptr;      size_t cap_far_ = 0;

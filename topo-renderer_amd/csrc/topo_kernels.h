@@ -42,6 +42,7 @@ struct FrameParams {
     const TileDev* tiles;      // n_tiles entries in draw order (BTreeMap order, terrain_renderer.rs:407)
     const ViewDev* views;      // n_views
     uint64_t* vis;             // n_views * W * H visibility keys: depth bits << 32 | id
+    uint8_t* dirty;            // one byte per 64 consecutive keys: 1 = some key of the segment was written this frame
     WorkItem* work;
     uint32_t* counters;        // [0] near work count, [1] big count, [2] status bits, [3] rare count, [4] far candidates,
                                // [5] far survivors, [6] big start, [7] rare start (of the current phase)
@@ -92,7 +93,7 @@ void launch_normals_edges(const TileDev* tiles, const EdgeJob* jobs, uint32_t n_
 void launch_normals_corners(const TileDev* tiles, const CornerJob* jobs, uint32_t n_jobs, uint32_t w, uint32_t h, hipStream_t s);
 
 // frame phase (render)
-void launch_clear(const FrameParams& p, hipStream_t s);
+void launch_clear(const FrameParams& p, hipStream_t s);   // re-initialises the marked segments and the queue counters
 void launch_cull(const FrameParams& p, hipStream_t s);
 void launch_raster(const FrameParams& p, int phase, hipStream_t s);   // phase 0: near list, 1: far survivors
 void launch_phase_mark(const FrameParams& p, hipStream_t s);

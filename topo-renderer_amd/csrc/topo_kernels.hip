@@ -21,8 +21,21 @@ namespace {
 // so the wave never waits for it, whereas reading the current key first (to skip fragments that cannot win) puts a
 // full memory round trip into every loop that emits fragments.  Measured on c4: k_raster 0.187 -> 0.158 ms,
 // k_raster_big 0.45 -> 0.37 ms without the pre-test (profiles/README.md).
-__device__ __forceinline__ void vis_min(uint64_t* p, uint64_t key) {
-    atomicMin(reinterpret_cast<unsigned long long*>(p), (unsigned long long)key);
+// The buffer is tracked in segments of 64 consecutive keys: whoever writes a key marks its segment (a plain byte
+// store of 1: racing writers agree), k_clear re-initialises only marked segments, and k_resolve does not even read
+// the keys of a block whose segments are all unmarked.  About half of a panorama is sky that no fragment touches.
+struct Vis {
+    uint64_t* p;             // this view's keys
+    const uint64_t* base;    // the whole buffer (segment numbers are global)
+    uint8_t* dirty;
+};
+__device__ __forceinline__ Vis view_vis(const FrameParams& P, uint32_t view) {
+    return Vis{P.vis + (size_t)view * P.W * P.H, P.vis, P.dirty};
+}
+__device__ __forceinline__ void vis_min(const Vis& v, size_t pix, uint64_t key) {
+    uint64_t* q = v.p + pix;
+    atomicMin(reinterpret_cast<unsigned long long*>(q), (unsigned long long)key);
+    v.dirty[(size_t)(q - v.base) >> 6] = 1;
 }
 
 // ======================================================================================================
@@ -168,14 +181,21 @@ __global__ __launch_bounds__(64) void k_normals_corner(const TileDev* __restrict
 // frame phase
 // ======================================================================================================
 
-__global__ __launch_bounds__(256) void k_clear(uint64_t* __restrict__ vis, size_t n, uint32_t* __restrict__ counters) {
+// Re-initialise the visibility buffer for a new frame: only the segments marked dirty are rewritten (and unmarked).
+// A wave takes 64 segments at a time: one coalesced read of their marks, then one 512-byte store per marked segment.
+__global__ __launch_bounds__(256) void k_clear(uint64_t* __restrict__ vis, uint8_t* __restrict__ dirty, size_t n,
+                                               uint32_t* __restrict__ counters) {
     if (blockIdx.x == 0 && threadIdx.x < 8 && threadIdx.x != 2) counters[threadIdx.x] = 0;   // all queue counters (status is sticky)
-    const size_t stride = (size_t)gridDim.x * blockDim.x * 2;
-    for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 2; i < n; i += stride) {
-        if (i + 1 < n) {
-            *reinterpret_cast<ulonglong2*>(vis + i) = make_ulonglong2(kVisClear, kVisClear);
-        } else {
-            vis[i] = kVisClear;
+    const uint32_t lane = threadIdx.x & 63;
+    const size_t nseg = (n + 63) >> 6, wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwave = (size_t)gridDim.x * 4;
+    for (size_t g = wave * 64; g < nseg; g += nwave * 64) {
+        const bool mine = g + lane < nseg && dirty[g + lane] != 0;
+        uint64_t todo = __ballot(mine);
+        if (mine) dirty[g + lane] = 0;
+        while (todo) {
+            const size_t seg = g + (size_t)__builtin_ctzll(todo);
+            todo &= todo - 1;
+            vis[seg * 64 + lane] = kVisClear;      // the buffer is allocated in whole segments
         }
     }
 }
@@ -354,12 +374,12 @@ __global__ void k_phase_mark(uint32_t* counters) {
 // ---- raster ------------------------------------------------------------------------------------------
 
 // Pixel loop of the generic (int64) path.
-__device__ __forceinline__ void raster_box(const TriSetup& ts, uint64_t* __restrict__ vis, int32_t W, uint32_t id,
+__device__ __forceinline__ void raster_box(const TriSetup& ts, const Vis& vis, int32_t W, uint32_t id,
                                            int32_t px0, int32_t px1, int32_t py0, int32_t py1) {
     for (int32_t py = py0; py <= py1; ++py)
         for (int32_t px = px0; px <= px1; ++px) {
             float z, b[3];
-            if (triangle_pixel(ts, px, py, z, b)) vis_min(vis + (size_t)py * W + px, vis_key(z, id));
+            if (triangle_pixel(ts, px, py, z, b)) vis_min(vis, (size_t)py * W + px, vis_key(z, id));
         }
 }
 
@@ -421,13 +441,13 @@ struct FragList {
 #endif
 constexpr int32_t kInlaneRows = TOPO_INLANE_ROWS, kInlaneCols = TOPO_INLANE_COLS;
 
-__device__ __forceinline__ void frag_push(FragList& fl, uint64_t* __restrict__ vis, uint32_t pix, uint64_t key) {
+__device__ __forceinline__ void frag_push(FragList& fl, const Vis& vis, uint32_t pix, uint64_t key) {
     const uint32_t slot = atomicAdd(&fl.count, 1u);
     if (slot < kFragCap) {
         fl.pix[slot] = pix;
         fl.key[slot] = key;
     } else {
-        vis_min(vis + pix, key);   // list full: fall back to the direct path
+        vis_min(vis, pix, key);   // list full: fall back to the direct path
     }
 }
 
@@ -473,7 +493,7 @@ __device__ __forceinline__ bool classify_small(const FrameParams& P, const SVert
 // row to its covered span (padded by a pixel either side); the exact integer test then decides every pixel, so
 // the estimate can only cost time, never change coverage.  Coverage, barycentrics and depth are the values
 // triangle_pixel() gives.
-__device__ __forceinline__ void raster_rows(FragList& fl, uint64_t* __restrict__ vis, int32_t W, int32_t H, int32_t X0, int32_t Y0,
+__device__ __forceinline__ void raster_rows(FragList& fl, const Vis& vis, int32_t W, int32_t H, int32_t X0, int32_t Y0,
                                             int32_t X1, int32_t Y1, int32_t X2, int32_t Y2, float z0, float z1, float z2,
                                             uint32_t id) {
     const int32_t mnx = min(X0, min(X1, X2)), mxx = max(X0, max(X1, X2));
@@ -545,7 +565,7 @@ __device__ __forceinline__ uint32_t tri_push(TriList& tl, uint32_t n, bool push,
 
 // Pop up to 64 listed triangles (the newest ones), one per lane, walk them, then flush the fragment list if it
 // holds a wave's worth (or unconditionally when `flush`).  Returns the remaining count.
-__device__ __forceinline__ uint32_t tri_drain(TriList& tl, FragList& fl, uint64_t* __restrict__ vis, int32_t W, int32_t H, uint32_t n,
+__device__ __forceinline__ uint32_t tri_drain(TriList& tl, FragList& fl, const Vis& vis, int32_t W, int32_t H, uint32_t n,
                                               bool flush) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t take = min(n, 64u), base = n - take;
@@ -555,7 +575,7 @@ __device__ __forceinline__ uint32_t tri_drain(TriList& tl, FragList& fl, uint64_
     }
     const uint32_t nfrag = min(fl.count, kFragCap);
     if (nfrag >= 64 || (flush && nfrag > 0)) {
-        for (uint32_t f = lane; f < nfrag; f += 64) vis_min(vis + fl.pix[f], fl.key[f]);
+        for (uint32_t f = lane; f < nfrag; f += 64) vis_min(vis, fl.pix[f], fl.key[f]);
         if (lane == 0) fl.count = 0;
     }
     return base;
@@ -608,7 +628,7 @@ __global__ __launch_bounds__(256, TOPO_RASTER_WAVES) void k_raster(FrameParams P
         const uint32_t ncx = min(kBCX, P.tile_w - 1 - x0);       // cells per row
         const uint32_t vx = x0 + lane;
         const bool vcol = lane < kVX && vx < P.tile_w;
-        uint64_t* vis = P.vis + (size_t)view_idx * P.W * P.H;
+        const Vis vis = view_vis(P, view_idx);
         // the view matrix, read once per block into scalar registers: left to the compiler it is re-loaded from
         // memory every row (it cannot prove the visibility-buffer atomics do not alias it) behind an
         // s_waitcnt vmcnt(0) that also drains the height prefetch
@@ -683,7 +703,7 @@ __global__ __launch_bounds__(256, TOPO_RASTER_WAVES) void k_raster(FrameParams P
         // block end: the list refers to this block's view, so it is emptied before the next item
         while (ntri > 0) ntri = tri_drain(tl, fl, vis, P.W, P.H, ntri, true);
         const uint32_t nfrag = min(fl.count, kFragCap);
-        for (uint32_t f = lane; f < nfrag; f += 64) vis_min(vis + fl.pix[f], fl.key[f]);
+        for (uint32_t f = lane; f < nfrag; f += 64) vis_min(vis, fl.pix[f], fl.key[f]);
         if (lane == 0) fl.count = 0;
     }
 }
@@ -696,7 +716,7 @@ __global__ __launch_bounds__(256) void k_raster_rare(FrameParams P) {
     for (uint32_t item = P.counters[7] + blockIdx.x * blockDim.x + threadIdx.x; item < count; item += gridDim.x * blockDim.x) {
         const RareItem ri = P.rare[item];
         const uint32_t rank = fastdiv(ri.draw, P.div_tris), tri = ri.draw - rank * P.tris_per_tile;
-        uint64_t* vis = P.vis + (size_t)ri.view * P.W * P.H;
+        const Vis vis = view_vis(P, ri.view);
         for (uint32_t fan = 0; fan < 2; ++fan) {
             ResolvedTri r;
             if (!resolve_triangle(P.tiles[rank], P.tile_w, P.div_hm1, P.tile_h - 1, P.views[ri.view], P.W, P.H, tri, fan, r)) continue;
@@ -721,20 +741,20 @@ __device__ __forceinline__ float unif(float v) { return __uint_as_float((uint32_
 #define TOPO_BIG_PRETEST_SMALL false
 #endif
 template <bool kPretest>
-__device__ __forceinline__ void vis_min4(uint64_t* __restrict__ vis, const uint32_t pix[4], const uint64_t key[4]) {
+__device__ __forceinline__ void vis_min4(const Vis& vis, const uint32_t pix[4], const uint64_t key[4]) {
     if (!kPretest) {
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            if (key[k] != kVisClear) atomicMin(reinterpret_cast<unsigned long long*>(vis + pix[k]), (unsigned long long)key[k]);
+            if (key[k] != kVisClear) vis_min(vis, pix[k], key[k]);
         return;
     }
     uint64_t cur[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-        cur[k] = key[k] != kVisClear ? __hip_atomic_load(vis + pix[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        cur[k] = key[k] != kVisClear ? __hip_atomic_load(vis.p + pix[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-        if (key[k] < cur[k]) atomicMin(reinterpret_cast<unsigned long long*>(vis + pix[k]), (unsigned long long)key[k]);
+        if (key[k] < cur[k]) vis_min(vis, pix[k], key[k]);
 }
 
 // One wave per BigItem: the item carries the snapped vertices, so every lane re-runs the exact integer setup
@@ -759,7 +779,7 @@ __global__ __launch_bounds__(256) void k_raster_big(FrameParams P) {
             for (int k = 0; k < 3; ++k) { bi.X[k] = uni(g.X[k]); bi.Y[k] = uni(g.Y[k]); bi.z[k] = unif(g.z[k]); }
         }
         if (bi.id == kNoTri) continue;
-        uint64_t* vis = P.vis + (size_t)bi.view * P.W * P.H;
+        const Vis vis = view_vis(P, bi.view);
         const int32_t rx = (int32_t)(bi.region & 0xFFFFu), ry = (int32_t)(bi.region >> 16);
         const int32_t X0 = bi.X[0], Y0 = bi.Y[0], X1 = bi.X[1], Y1 = bi.Y[1], X2 = bi.X[2], Y2 = bi.Y[2];
         const int32_t mnx = min(X0, min(X1, X2)), mxx = max(X0, max(X1, X2));
@@ -859,7 +879,7 @@ __global__ __launch_bounds__(256) void k_raster_big(FrameParams P) {
                     float z = fmaf(f1 * ts.iA, ts.dz1, fmaf(f2 * ts.iA, ts.dz2, ts.z0));
                     if (z < 1.0f) {
                         if (z < 0.0f) z = 0.0f;
-                        vis_min(vis + (size_t)py * P.W + px, vis_key(z, bi.id));
+                        vis_min(vis, (size_t)py * P.W + px, vis_key(z, bi.id));
                     }
                 }
                 F0 += ax0; F1 += ax1; F2 += ax2;
@@ -879,7 +899,7 @@ __global__ __launch_bounds__(256) void k_raster_big(FrameParams P) {
 #define TOPO_RESOLVE_ROWS 16
 #endif
 #ifndef TOPO_RESOLVE_WGS
-#define TOPO_RESOLVE_WGS 6
+#define TOPO_RESOLVE_WGS 5
 #endif
 constexpr int kResolveRows = TOPO_RESOLVE_ROWS;
 __global__ __launch_bounds__(256, TOPO_RESOLVE_WGS) void k_resolve(FrameParams P, OutputParams O) {
@@ -894,7 +914,29 @@ __global__ __launch_bounds__(256, TOPO_RESOLVE_WGS) void k_resolve(FrameParams P
     const uint32_t view_idx = blockIdx.z;
     const uint64_t* vis = P.vis + (size_t)view_idx * P.W * P.H;
     const int32_t bx = blockIdx.x * 64, by = blockIdx.y * kResolveRows;
+    // every row of the block + halo spans at most three 64-key segments: if none of them is marked, nothing was drawn here
     bool terrain = false;
+    if (threadIdx.x < (kResolveRows + 2) * 3) {
+        const int32_t row = (int32_t)threadIdx.x / 3, k = (int32_t)threadIdx.x - row * 3;
+        int32_t y = by + row - 1;
+        y = y < 0 ? 0 : (y > P.H - 1 ? P.H - 1 : y);
+        const int32_t x0 = bx > 0 ? bx - 1 : 0, x1 = bx + 64 < P.W ? bx + 64 : P.W - 1;
+        const size_t first = (size_t)(vis - P.vis) + (size_t)y * P.W;
+        const size_t seg = ((first + x0) >> 6) + k;
+        terrain = seg <= ((first + x1) >> 6) && P.dirty[seg] != 0;
+    }
+    if (__syncthreads_or(terrain) == 0) {        // workgroup-uniform: write the cleared texel and depth 1
+        const int32_t px = bx + (int32_t)(threadIdx.x & 63);
+        if (px >= P.W) return;
+        for (int32_t ty = threadIdx.x >> 6; ty < kResolveRows && by + ty < P.H; ty += 4) {
+            *reinterpret_cast<uint32_t*>(O.rgba + (size_t)view_idx * O.rgba_view_stride + (size_t)(by + ty) * O.rgba_pitch + (size_t)px * 4) = P.sky_c8;
+            if (O.depth)
+                *reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(O.depth) + (size_t)view_idx * O.depth_view_stride +
+                                          (size_t)(by + ty) * O.depth_pitch + (size_t)px * 4) = 1.0f;
+        }
+        return;
+    }
+    terrain = false;
     for (int idx = threadIdx.x; idx < (kResolveRows + 2) * 66; idx += 256) {
         const int ly = idx / 66, lx = idx - ly * 66;
         int32_t x = bx + lx - 1, y = by + ly - 1;
@@ -1043,7 +1085,7 @@ void launch_normals_corners(const TileDev* tiles, const CornerJob* jobs, uint32_
 
 void launch_clear(const FrameParams& p, hipStream_t s) {
     const size_t n = (size_t)p.n_views * p.W * p.H;
-    hipLaunchKernelGGL(k_clear, dim3(2048), dim3(256), 0, s, p.vis, n, p.counters);
+    hipLaunchKernelGGL(k_clear, dim3(2048), dim3(256), 0, s, p.vis, p.dirty, n, p.counters);
 }
 
 void launch_cull(const FrameParams& p, hipStream_t s) {
