@@ -404,3 +404,53 @@ def test_full_size_config4_sectors_against_oracle(topo, orc):
     ro, do = o.render_views(pick, threads=2)
     for k in range(2):
         assert_same_frame((rg[k], dg[k]), (ro[k], do[k]), f"config-4 sector {k}")
+
+
+def test_frame_sequence_on_one_renderer(topo, orc):
+    """State carried between frames (the touched-segment marks of the visibility buffer, grow-only buffers, the
+    queues): one renderer draws a sequence of frames of changing size, direction and scene -- terrain turning into
+    sky and back, a smaller frame after a larger one, a width that is not a multiple of 64 px, a tile unloaded and
+    re-added -- and every frame must equal the oracle's (same call history; its z-buffer starts from scratch each frame)."""
+    import torch
+    sc = Scene(64, 2, 2, eye_dh=60)
+    g, o = both(topo, orc, 64, 64)
+    sc.load(g)
+    sc.load(o)
+    seq = [  # (W, H, yaw, pitch, fov, mode, action)
+        (256, 192, 20, 10, 70, 0, None),
+        (256, 192, 20, -80, 70, 0, None),            # all sky: every mark of the previous frame must have been undone
+        (256, 192, 200, 35, 70, 1, None),
+        (96, 80, 200, 35, 70, 0, None),              # smaller frame inside the same buffers
+        (333, 117, 75, 5, 100, 2, None),             # row length not a multiple of the 64-key segment
+        (333, 117, 75, 5, 100, 0, ("unload", sc.locs[0])),
+        (320, 256, 310, 15, 60, 0, ("add", sc.locs[0])),
+        (320, 256, 310, -89, 60, 0, None),
+        (320, 256, 130, 60, 120, 0, None),
+    ]
+    for i, (W, H, yaw, pitch, fov, mode, action) in enumerate(seq):
+        if action:
+            kind, loc = action
+            for r in (g, o):
+                if kind == "unload":
+                    r.unload_terrain(*loc)
+                else:
+                    r.add_terrain(loc[0], loc[1], sc.heights[loc], *sc.transform(loc))
+        u, pu = sc.uniforms(W, H, yaw, pitch, fov, mode), topo.post_uniforms(W, H)
+        g.update(W, H, u, pu)
+        o.update(W, H, u, pu)
+        assert_same_frame(g.render(), o.render(), f"sequence frame {i}")
+    # several views per submission after single-view frames, and back
+    views = sc.panorama(96, 64, yaw0_deg=10)
+    strip = torch.empty((8, 64, 96, 4), dtype=torch.uint8, device="cuda")
+    depth = torch.empty((8, 64, 96), dtype=torch.float32, device="cuda")
+    for _ in range(2):
+        g.render_views_device(views, 96, 64, strip.data_ptr(), 64 * 96 * 4, 96 * 4, depth.data_ptr(), 64 * 96 * 4, 96 * 4)
+        g.synchronize()
+        for k in (0, 3, 7):
+            o.update(96, 64, views[k], topo.post_uniforms(96, 64))
+            assert_same_frame((strip[k].cpu().numpy(), depth[k].cpu().numpy()), o.render(), f"sequence panorama sector {k}")
+        W, H = 128, 128
+        u, pu = sc.uniforms(W, H, 45, -70, 60, 0), topo.post_uniforms(W, H)
+        g.update(W, H, u, pu)
+        o.update(W, H, u, pu)
+        assert_same_frame(g.render(), o.render(), "sequence: single frame after a panorama")
