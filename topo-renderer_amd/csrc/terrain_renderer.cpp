@@ -170,7 +170,8 @@ int TerrainRenderer::add_terrain(int32_t lat, int32_t lon, const float* heights,
     TOPO_HIP_TRY(hipMalloc((void**)&t.d_heights, texels * 4));
     hipError_t e = hipMalloc((void**)&t.d_normals, texels * 4);
     // one allocation: block min/max (2 floats per block), then the sin/cos tables of the w columns and the h rows
-    if (e == hipSuccess) e = hipMalloc((void**)&t.d_minmax, ((size_t)bxc * byc * 2 + 2 * ((size_t)w + h)) * sizeof(float));
+    const size_t tile_floats = (size_t)bxc * byc * 2 + 2 * ((size_t)w + h);   // even: the f64 block bounds that follow stay 8-byte aligned
+    if (e == hipSuccess) e = hipMalloc((void**)&t.d_minmax, tile_floats * sizeof(float) + (size_t)bxc * byc * 16 * sizeof(double));
     if (e == hipSuccess) e = hipMemcpyAsync(t.d_heights, heights, texels * 4, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream_);
     // (the zero-initialised normal texture: k_normals_interior writes the untouched border ring as zero)
     if (e != hipSuccess) {
@@ -183,6 +184,7 @@ int TerrainRenderer::add_terrain(int32_t lat, int32_t lon, const float* heights,
     t.dev.block_minmax = t.d_minmax;
     t.dev.trig_lon = t.d_minmax + (size_t)bxc * byc * 2;
     t.dev.trig_lat = t.dev.trig_lon + 2 * (size_t)w;
+    t.dev.block_bounds = reinterpret_cast<const double*>(t.d_minmax + tile_floats);
     t.dev.raster_x = rp[0]; t.dev.raster_y = rp[1];
     t.dev.model_x = mp[0]; t.dev.model_y = mp[1];
     t.dev.scale_x = ps[0]; t.dev.scale_y = ps[1];

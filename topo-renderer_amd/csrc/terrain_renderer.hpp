@@ -87,7 +87,7 @@ class TerrainRenderer {
     bool table_dirty_ = true;
     int lds_rows_ = 16;
     uint32_t big_cap_cfg_ = 0, rare_cap_cfg_ = 0;
-    float occlusion_split_m_ = 60000.0f;
+    float occlusion_split_m_ = 90000.0f;   // flat optimum 60..120 km at c4 (profiles/README.md)
 
     hipStream_t own_stream_ = nullptr, stream_ = nullptr;
     static constexpr int kNumEvents = 11;

@@ -42,6 +42,9 @@ __device__ __forceinline__ void vis_min(const Vis& v, size_t pix, uint64_t key) 
 // load phase
 // ======================================================================================================
 
+struct SinCos64 { double s, c; };
+__device__ __forceinline__ SinCos64 sincos64(double a) { SinCos64 r; r.s = sin(a); r.c = cos(a); return r; }
+
 // min/max height of the (kVX x kVY) vertices of every raster block, one wave per block; the first (w + h) / 64
 // waves also fill one entry each of the tile's sin/cos tables (TileDev::trig_lon / trig_lat).
 __global__ __launch_bounds__(64) void k_block_minmax(TileDev t, uint32_t w, uint32_t h, uint32_t bx_count) {
@@ -66,6 +69,36 @@ __global__ __launch_bounds__(64) void k_block_minmax(TileDev t, uint32_t w, uint
     if (threadIdx.x == 0) {
         minmax[2 * blk] = mn;
         minmax[2 * blk + 1] = mx;
+        // the view-independent half of the cull, in f64: bounding sphere of the block's patch and its corner directions
+        const double x0 = (double)(bx * kBCX), y0 = (double)(by * kBCY);
+        double x1 = x0 + (double)kBCX, y1 = y0 + (double)kBCY;
+        if (x1 > (double)(w - 1)) x1 = (double)(w - 1);
+        if (y1 > (double)(h - 1)) y1 = (double)(h - 1);
+        const double hmin = (double)mn, hmax = (double)mx, hmid = 0.5 * (hmin + hmax);
+        const double D2R = 0.017453292519943295;
+        auto lon_of = [&](double vx) { return ((vx - (double)t.raster_x) * (double)t.scale_x + (double)t.model_x) * D2R; };
+        auto lat_of = [&](double vy) { return ((vy - (double)t.raster_y) * -(double)t.scale_y + (double)t.model_y) * D2R; };
+        const SinCos64 lo[2] = {sincos64(lon_of(x0)), sincos64(lon_of(x1))}, la[2] = {sincos64(lat_of(y0)), sincos64(lat_of(y1))};
+        const SinCos64 loc = sincos64(lon_of(0.5 * (x0 + x1))), lac = sincos64(lat_of(0.5 * (y0 + y1)));
+        double* bs = const_cast<double*>(t.block_bounds) + (size_t)blk * 4;                              // sphere
+        double* bb = const_cast<double*>(t.block_bounds) + (size_t)gridDim.x * 4 + (size_t)blk * 12;       // corner directions
+        double u[4][3];
+        for (int k = 0; k < 4; ++k) {
+            const SinCos64 &o = lo[k & 1], &a = la[k >> 1];
+            u[k][0] = a.c * o.c; u[k][1] = a.c * o.s; u[k][2] = a.s;
+            bb[3 * k] = u[k][0]; bb[3 * k + 1] = u[k][1]; bb[3 * k + 2] = u[k][2];
+        }
+        const double Rm = (double)kR0 + hmid;
+        const double c[3] = {Rm * lac.c * loc.c, Rm * lac.c * loc.s, Rm * lac.s};
+        double r2 = 0.0;
+        for (int k = 0; k < 4; ++k) {
+            const double dx = Rm * u[k][0] - c[0], dy = Rm * u[k][1] - c[1], dz = Rm * u[k][2] - c[2];
+            const double d2 = dx * dx + dy * dy + dz * dz;
+            r2 = d2 > r2 ? d2 : r2;
+        }
+        // corners bound the patch up to its sagitta (< 1 m for a 6 km block); + half the height range + margin
+        bs[0] = c[0]; bs[1] = c[1]; bs[2] = c[2];
+        bs[3] = sqrt(r2) + 0.5 * (hmax - hmin) + 8.0 + 64.0;
     }
     for (uint32_t e = blk * 64 + threadIdx.x; e < w + h; e += gridDim.x * 64) {
         float sn, cs;
@@ -208,8 +241,23 @@ __global__ __launch_bounds__(256) void k_clear(uint64_t* __restrict__ vis, uint8
 #endif
 constexpr uint32_t kStrip = TOPO_NEAR_STRIP;      // cell rows per near-block strip (terrain_renderer.cpp sizes the list for >= 2)
 
-struct SinCos64 { double s, c; };
-__device__ __forceinline__ SinCos64 sincos64(double a) { SinCos64 r; r.s = sin(a); r.c = cos(a); return r; }
+// Clip plane `pl` of a column-major view-projection matrix as (a, b, c, d, |(a, b, c)|): 0..3 = w +- x, w +- y,
+// 4 = near (z_clip >= 0), 5 = w - z.
+__device__ __forceinline__ void clip_plane(const float* m, int pl, double out[5]) {
+    double a, b, cc, d;
+    const int row = pl >> 1;            // 0: x, 1: y, 2: z
+    const double sgn = (pl & 1) ? -1.0 : 1.0;
+    if (pl == 4) {                      // near: z_clip >= 0
+        a = m[2]; b = m[6]; cc = m[10]; d = m[14];
+    } else {                            // w +- row
+        a = (double)m[3] + sgn * (double)m[row];
+        b = (double)m[7] + sgn * (double)m[4 + row];
+        cc = (double)m[11] + sgn * (double)m[8 + row];
+        d = (double)m[15] + sgn * (double)m[12 + row];
+    }
+    out[0] = a; out[1] = b; out[2] = cc; out[3] = d;
+    out[4] = sqrt(a * a + b * b + cc * cc);
+}
 
 // One lane per (view, tile, block).  f64 throughout; everything here is a conservative, result-neutral filter:
 //  * frustum: the block's bounding sphere (inflated by 72 m for the f32 noise of the real vertex path) against the
@@ -219,73 +267,83 @@ __device__ __forceinline__ SinCos64 sincos64(double a) { SinCos64 r; r.s = sin(a
 //    slab -- the lat/lon rectangle of its vertices x [hmin - 1 m, hmax + 2 m], which contains every triangle of the
 //    block up to < 1 m of chord sagitta -- and records the pixel box (+-2 px) and a lower bound of the depths
 //    (z_ndc at the smallest corner w, minus 8/w: the f32 clip-space cancellation noise is ~1 clip unit).
+// Emit a block the raster must visit.  With the occlusion filter on, such blocks are few and heavy (large triangles),
+// so each is cut into strips of kStrip cell rows to spread them over the resident waves:
+// block = id | first cell row << 24 | rows << 28 (rows 0 = the whole block).
+__device__ __forceinline__ void emit_near(const FrameParams& P, uint32_t view, uint32_t rank, uint32_t blk) {
+    if (P.split_m > 0.0f) {
+        const uint32_t by = blk / P.bx_count;
+        const uint32_t cell_rows = min(kBCY, P.tile_h - 1 - by * kBCY);
+        const uint32_t n = (cell_rows + kStrip - 1) / kStrip;
+        const uint32_t base = atomicAdd(&P.counters[0], n);
+        for (uint32_t k = 0; k < n; ++k)
+            if (base + k < P.near_cap)
+                P.work[base + k] = WorkItem{(view << 16) | rank, blk | ((kStrip * k) << 24) | (min(kStrip, cell_rows - kStrip * k) << 28)};
+        return;
+    }
+    const uint32_t slot = atomicAdd(&P.counters[0], 1u);
+    if (slot < P.near_cap) P.work[slot] = WorkItem{(view << 16) | rank, blk};
+}
+
 __global__ __launch_bounds__(256) void k_cull(FrameParams P) {
     const uint32_t blocks_per_tile = P.bx_count * P.by_count;
     const size_t total = (size_t)P.n_views * P.n_tiles * blocks_per_tile;
-    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= total) return;
-    const uint32_t blk = (uint32_t)(gid % blocks_per_tile);
-    const uint32_t rank = (uint32_t)((gid / blocks_per_tile) % P.n_tiles);
-    const uint32_t view = (uint32_t)(gid / ((size_t)blocks_per_tile * P.n_tiles));
-    const TileDev& t = P.tiles[rank];
-    const uint32_t bx = blk % P.bx_count, by = blk / P.bx_count;
-    const double x0 = (double)(bx * kBCX), y0 = (double)(by * kBCY);
-    double x1 = x0 + (double)kBCX, y1 = y0 + (double)kBCY;
-    if (x1 > (double)(P.tile_w - 1)) x1 = (double)(P.tile_w - 1);
-    if (y1 > (double)(P.tile_h - 1)) y1 = (double)(P.tile_h - 1);
-    const double hmin = (double)t.block_minmax[2 * blk], hmax = (double)t.block_minmax[2 * blk + 1];
-    const double hmid = 0.5 * (hmin + hmax);
-    const double D2R = 0.017453292519943295;
-    auto lon_of = [&](double vx) { return ((vx - (double)t.raster_x) * (double)t.scale_x + (double)t.model_x) * D2R; };
-    auto lat_of = [&](double vy) { return ((vy - (double)t.raster_y) * -(double)t.scale_y + (double)t.model_y) * D2R; };
-    const SinCos64 lo[2] = {sincos64(lon_of(x0)), sincos64(lon_of(x1))}, la[2] = {sincos64(lat_of(y0)), sincos64(lat_of(y1))};
-    const SinCos64 loc = sincos64(lon_of(0.5 * (x0 + x1))), lac = sincos64(lat_of(0.5 * (y0 + y1)));
-    // unit directions of the four corners and the centre
-    double u[4][3];
-    for (int k = 0; k < 4; ++k) {
-        const SinCos64 &o = lo[k & 1], &a = la[k >> 1];
-        u[k][0] = a.c * o.c; u[k][1] = a.c * o.s; u[k][2] = a.s;
-    }
-    const double Rm = (double)kR0 + hmid;
-    const double c[3] = {Rm * lac.c * loc.c, Rm * lac.c * loc.s, Rm * lac.s};
-    double r2 = 0.0;
-    for (int k = 0; k < 4; ++k) {
-        const double dx = Rm * u[k][0] - c[0], dy = Rm * u[k][1] - c[1], dz = Rm * u[k][2] - c[2];
-        const double d2 = dx * dx + dy * dy + dz * dz;
-        r2 = d2 > r2 ? d2 : r2;
-    }
-    // corners bound the patch up to its sagitta (< 1 m for a 6 km block); + half the height range + margin
-    const double radius = sqrt(r2) + 0.5 * (hmax - hmin) + 8.0 + 64.0;
-    const float* m = P.views[view].proj;
-    bool keep = true;
-    for (int pl = 0; pl < 6 && keep; ++pl) {
-        double a, b, cc, d;
-        const int row = pl >> 1;            // 0: x, 1: y, 2: z
-        const double sgn = (pl & 1) ? -1.0 : 1.0;
-        if (pl == 4) {                      // near: z_clip >= 0
-            a = m[2]; b = m[6]; cc = m[10]; d = m[14];
-        } else {                            // w +- row
-            a = (double)m[3] + sgn * (double)m[row];
-            b = (double)m[7] + sgn * (double)m[4 + row];
-            cc = (double)m[11] + sgn * (double)m[8 + row];
-            d = (double)m[15] + sgn * (double)m[12 + row];
+    const size_t gid0 = (size_t)blockIdx.x * blockDim.x, gid = gid0 + threadIdx.x;
+    // the six clip planes (and their norms) of the first two views this workgroup can meet, once per workgroup
+    __shared__ double s_plane[2][6][5];
+    __shared__ uint32_t s_far[256], s_nfar;      // lanes whose block is an occlusion-test candidate
+    const uint32_t view0 = (uint32_t)(gid0 / ((size_t)blocks_per_tile * P.n_tiles));
+    if (threadIdx.x < 12 && view0 + threadIdx.x / 6 < P.n_views) clip_plane(P.views[view0 + threadIdx.x / 6].proj, threadIdx.x % 6, s_plane[threadIdx.x / 6][threadIdx.x % 6]);
+    if (threadIdx.x == 0) s_nfar = 0;
+    __syncthreads();
+    // ---- phase A, one lane per (view, tile, block): frustum test, then near / far classification
+    if (gid < total) {
+        const uint32_t blk = (uint32_t)(gid % blocks_per_tile);
+        const uint32_t rank = (uint32_t)((gid / blocks_per_tile) % P.n_tiles);
+        const uint32_t view = (uint32_t)(gid / ((size_t)blocks_per_tile * P.n_tiles));
+        const TileDev& t = P.tiles[rank];
+        const double hmin = (double)t.block_minmax[2 * blk], hmax = (double)t.block_minmax[2 * blk + 1];
+        const double* bs = t.block_bounds + (size_t)blk * 4;      // bounding sphere from the load phase
+        const double c[3] = {bs[0], bs[1], bs[2]}, radius = bs[3];
+        const float* m = P.views[view].proj;
+        bool keep = true;
+        for (int pl = 0; pl < 6 && keep; ++pl) {
+            double own[5];
+            const double* q = s_plane[view - view0 < 2 ? view - view0 : 0][pl];
+            if (view - view0 >= 2) {            // tiny mosaics: more than two views per workgroup
+                clip_plane(m, pl, own);
+                q = own;
+            }
+            const double dist = q[0] * c[0] + q[1] * c[1] + q[2] * c[2] + q[3];
+            if (dist < -radius * q[4]) keep = false;
         }
-        const double dist = a * c[0] + b * c[1] + cc * c[2] + d;
-        const double nrm = sqrt(a * a + b * b + cc * cc);
-        if (dist < -radius * nrm) keep = false;
+        const bool sane = hmin <= hmax;         // NaN heights: no filtering at all, the raster path deals with it
+        if (!sane) keep = true;
+        if (keep) {
+            // view depth of the nearest point the block can contain
+            const double wn = sqrt((double)m[3] * m[3] + (double)m[7] * m[7] + (double)m[11] * m[11]);
+            const double w_near = ((double)m[3] * c[0] + (double)m[7] * c[1] + (double)m[11] * c[2] + (double)m[15]) - radius * wn;
+            if (sane && P.split_m > 0.0f && w_near > (double)P.split_m) s_far[atomicAdd(&s_nfar, 1u)] = threadIdx.x;
+            else emit_near(P, view, rank, blk);
+        }
     }
-    const bool sane = hmin <= hmax;         // NaN heights: no filtering at all, the raster path deals with it
-    if (!sane) keep = true;
-    if (!keep) return;
-    // view depth of the nearest point the block can contain
-    const double wn = sqrt((double)m[3] * m[3] + (double)m[7] * m[7] + (double)m[11] * m[11]);
-    const double w_near = ((double)m[3] * c[0] + (double)m[7] * c[1] + (double)m[11] * c[2] + (double)m[15]) - radius * wn;
-    if (sane && P.split_m > 0.0f && w_near > (double)P.split_m) {
+    __syncthreads();
+    // ---- phase B, one lane per candidate (they are ~10 % of the lanes, scattered: handled in place, every wave would
+    // pay for the f64 projection of the eight slab corners)
+    for (uint32_t i = threadIdx.x; i < s_nfar; i += blockDim.x) {
+        const size_t g = gid0 + s_far[i];
+        const uint32_t blk = (uint32_t)(g % blocks_per_tile);
+        const uint32_t rank = (uint32_t)((g / blocks_per_tile) % P.n_tiles);
+        const uint32_t view = (uint32_t)(g / ((size_t)blocks_per_tile * P.n_tiles));
+        const TileDev& t = P.tiles[rank];
+        const double hmin = (double)t.block_minmax[2 * blk], hmax = (double)t.block_minmax[2 * blk + 1];
+        const double* bb = t.block_bounds + (size_t)blocks_per_tile * 4 + (size_t)blk * 12;   // corner directions
+        const float* m = P.views[view].proj;
         double bxlo = 1e30, bxhi = -1e30, bylo = 1e30, byhi = -1e30, wmin = 1e30, zclip_at_wmin = 0.0;
         const double hs[2] = {hmin - 1.0, hmax + 2.0};
         for (int k = 0; k < 8; ++k) {
             const double R = (double)kR0 + hs[k >> 2];
-            const double px = R * u[k & 3][0], py = R * u[k & 3][1], pz = R * u[k & 3][2];
+            const double px = R * bb[3 * (k & 3)], py = R * bb[3 * (k & 3) + 1], pz = R * bb[3 * (k & 3) + 2];
             const double cx = (double)m[0] * px + (double)m[4] * py + (double)m[8] * pz + (double)m[12];
             const double cy = (double)m[1] * px + (double)m[5] * py + (double)m[9] * pz + (double)m[13];
             const double cz = (double)m[2] * px + (double)m[6] * py + (double)m[10] * pz + (double)m[14];
@@ -299,37 +357,25 @@ __global__ __launch_bounds__(256) void k_cull(FrameParams P) {
         // hull its minimum sits at the corner with the smallest w.  The real pipeline computes z_clip and w as f32
         // fma chains over ~6.4e6-sized terms: each carries up to ~1 (metre-sized clip units) of cancellation noise,
         // i.e. z_ndc is only good to ~2 / w.  Shave 8 / w.
-        double zmin = zclip_at_wmin / wmin - 8.0 / wmin;
-        if (wmin > 1000.0 && zmin > 0.0 && zmin < 1.0) {
-            const int32_t ix0 = max((int32_t)floor(bxlo) - 2, 0), ix1 = min((int32_t)ceil(bxhi) + 2, P.W - 1);
-            const int32_t iy0 = max((int32_t)floor(bylo) - 2, 0), iy1 = min((int32_t)ceil(byhi) + 2, P.H - 1);
-            if (ix0 > ix1 || iy0 > iy1) return;     // wholly outside the target even with the margin
-            float zf = (float)zmin;
-            if ((double)zf > zmin) zf = bits_f(f_bits(zf) - 1u);      // round down
-            const uint32_t slot = atomicAdd(&P.counters[4], 1u);
-            if (slot < P.work_cap) {
-                FarItem fi;
-                fi.view_rank = (view << 16) | rank; fi.block = blk;
-                fi.x0 = (uint16_t)ix0; fi.x1 = (uint16_t)ix1; fi.y0 = (uint16_t)iy0; fi.y1 = (uint16_t)iy1;
-                fi.zmin_bits = f_bits(zf);
-                P.far[slot] = fi;
-            }
-            return;
+        const double zmin = zclip_at_wmin / wmin - 8.0 / wmin;
+        if (!(wmin > 1000.0 && zmin > 0.0 && zmin < 1.0)) {
+            emit_near(P, view, rank, blk);          // no usable bound: rasterise it with the near blocks
+            continue;
+        }
+        const int32_t ix0 = max((int32_t)floor(bxlo) - 2, 0), ix1 = min((int32_t)ceil(bxhi) + 2, P.W - 1);
+        const int32_t iy0 = max((int32_t)floor(bylo) - 2, 0), iy1 = min((int32_t)ceil(byhi) + 2, P.H - 1);
+        if (ix0 > ix1 || iy0 > iy1) continue;       // wholly outside the target even with the margin
+        float zf = (float)zmin;
+        if ((double)zf > zmin) zf = bits_f(f_bits(zf) - 1u);      // round down
+        const uint32_t slot = atomicAdd(&P.counters[4], 1u);
+        if (slot < P.work_cap) {
+            FarItem fi;
+            fi.view_rank = (view << 16) | rank; fi.block = blk;
+            fi.x0 = (uint16_t)ix0; fi.x1 = (uint16_t)ix1; fi.y0 = (uint16_t)iy0; fi.y1 = (uint16_t)iy1;
+            fi.zmin_bits = f_bits(zf);
+            P.far[slot] = fi;
         }
     }
-    // a near block: with the occlusion filter on these are few and heavy (large triangles), so each is cut into
-    // strips of kStrip cell rows to spread them over the resident waves.  block = id | first cell row << 24 | rows << 28
-    if (P.split_m > 0.0f) {
-        const uint32_t cell_rows = min(kBCY, P.tile_h - 1 - by * kBCY);
-        const uint32_t n = (cell_rows + kStrip - 1) / kStrip;
-        const uint32_t base = atomicAdd(&P.counters[0], n);
-        for (uint32_t k = 0; k < n; ++k)
-            if (base + k < P.near_cap)
-                P.work[base + k] = WorkItem{(view << 16) | rank, blk | ((kStrip * k) << 24) | (min(kStrip, cell_rows - kStrip * k) << 28)};
-        return;
-    }
-    const uint32_t slot = atomicAdd(&P.counters[0], 1u);
-    if (slot < P.near_cap) P.work[slot] = WorkItem{(view << 16) | rank, blk};     // rows field 0 = the whole block
 }
 
 // One wave per far candidate: the block is dropped iff EVERY pixel of its footprint already holds a depth below
