@@ -450,8 +450,11 @@ static inline int64_t floor_div(int64_t a, int64_t b) { /* b > 0 */
 }
 
 /* Fixed-function state: CCW front, back-cull, Depth32F Less + write, REPLACE (pipeline.rs:221-246). */
+/* `orig` (non-null for the pieces of a primitive cut by the near plane): the primitive's own three vertices.  Coverage
+ * and depth of a piece come from the piece; its varyings are evaluated on the ORIGINAL primitive with homogeneous
+ * (clip-space) barycentrics, as clippers hand them to the attribute interpolators -- DESIGN.md "Raster spec" 8. */
 void raster_triangle(Frame& f, const Uniforms& u, const VSOut& v0, const VSOut& v1, const VSOut& v2,
-                     const ScreenVert& s0, const ScreenVert& s1, const ScreenVert& s2) {
+                     const ScreenVert& s0, const ScreenVert& s1, const ScreenVert& s2, const VSOut* const* orig = nullptr) {
     /* signed doubled area in y-down framebuffer space; visually counter-clockwise <=> negative */
     int64_t area2 = (s1.X - s0.X) * (s2.Y - s0.Y) - (s1.Y - s0.Y) * (s2.X - s0.X);
     if (area2 >= 0) return; /* back-facing or degenerate */
@@ -489,16 +492,30 @@ void raster_triangle(Frame& f, const Uniforms& u, const VSOut& v0, const VSOut& 
             if (z < 0.0f) z = 0.0f;
             const size_t p = (size_t)py * f.W + (size_t)px;
             if (!(z < f.depth[p])) continue; /* CompareFunction::Less */
-            /* perspective-correct varyings */
-            const float q0 = b0 * (1.0f / s0.w), q1 = b1 * (1.0f / s1.w), q2 = b2 * (1.0f / s2.w);
+            /* perspective-correct varyings: weights q_i, a = (a0 q0 + a1 q1 + a2 q2) / (q0 + q1 + q2) */
+            const VSOut *a0 = &v0, *a1 = &v1, *a2 = &v2;
+            float q0, q1, q2;
+            if (!orig) {
+                q0 = b0 * (1.0f / s0.w); q1 = b1 * (1.0f / s1.w); q2 = b2 * (1.0f / s2.w);
+            } else {
+                /* the pixel centre as a clip-space direction (gx, gy, 1); q = adj([x y w columns]) . (gx, gy, 1) */
+                a0 = orig[0]; a1 = orig[1]; a2 = orig[2];
+                const float gx = fmaf((float)px + 0.5f, 2.0f / (float)f.W, -1.0f);
+                const float gy = fmaf(-((float)py + 0.5f), 2.0f / (float)f.H, 1.0f);
+                auto det = [](float a, float b, float c, float d) { const float p = a * b, q = c * d; return p - q; };
+                const float *c0 = a0->clip, *c1 = a1->clip, *c2 = a2->clip;
+                q0 = fmaf(det(c1[1], c2[3], c1[3], c2[1]), gx, fmaf(det(c1[3], c2[0], c1[0], c2[3]), gy, det(c1[0], c2[1], c1[1], c2[0])));
+                q1 = fmaf(det(c2[1], c0[3], c2[3], c0[1]), gx, fmaf(det(c2[3], c0[0], c2[0], c0[3]), gy, det(c2[0], c0[1], c2[1], c0[0])));
+                q2 = fmaf(det(c0[1], c1[3], c0[3], c1[1]), gx, fmaf(det(c0[3], c1[0], c0[0], c1[3]), gy, det(c0[0], c1[1], c0[1], c1[0])));
+            }
             const float rq = 1.0f / ((q0 + q1) + q2);
             v3 wpos, wnrm;
-            wpos.x = fmaf(v2.wpos.x, q2, fmaf(v1.wpos.x, q1, v0.wpos.x * q0)) * rq;
-            wpos.y = fmaf(v2.wpos.y, q2, fmaf(v1.wpos.y, q1, v0.wpos.y * q0)) * rq;
-            wpos.z = fmaf(v2.wpos.z, q2, fmaf(v1.wpos.z, q1, v0.wpos.z * q0)) * rq;
-            wnrm.x = fmaf(v2.wnrm.x, q2, fmaf(v1.wnrm.x, q1, v0.wnrm.x * q0)) * rq;
-            wnrm.y = fmaf(v2.wnrm.y, q2, fmaf(v1.wnrm.y, q1, v0.wnrm.y * q0)) * rq;
-            wnrm.z = fmaf(v2.wnrm.z, q2, fmaf(v1.wnrm.z, q1, v0.wnrm.z * q0)) * rq;
+            wpos.x = fmaf(a2->wpos.x, q2, fmaf(a1->wpos.x, q1, a0->wpos.x * q0)) * rq;
+            wpos.y = fmaf(a2->wpos.y, q2, fmaf(a1->wpos.y, q1, a0->wpos.y * q0)) * rq;
+            wpos.z = fmaf(a2->wpos.z, q2, fmaf(a1->wpos.z, q1, a0->wpos.z * q0)) * rq;
+            wnrm.x = fmaf(a2->wnrm.x, q2, fmaf(a1->wnrm.x, q1, a0->wnrm.x * q0)) * rq;
+            wnrm.y = fmaf(a2->wnrm.y, q2, fmaf(a1->wnrm.y, q1, a0->wnrm.y * q0)) * rq;
+            wnrm.z = fmaf(a2->wnrm.z, q2, fmaf(a1->wnrm.z, q1, a0->wnrm.z * q0)) * rq;
             float c[4];
             fs_main(u, (float)px + 0.5f, (float)py + 0.5f, wpos, wnrm, c);
             f.depth[p] = z;
@@ -558,7 +575,7 @@ void draw_triangle(Frame& f, const Uniforms& u, const PV& pa, const PV& pb, cons
     ScreenVert sp[4];
     for (int k = 0; k < n; ++k)
         if (!to_screen(poly[k], f.W, f.H, &sp[k])) return; /* guard band: whole primitive discarded */
-    for (int k = 1; k + 1 < n; ++k) raster_triangle(f, u, poly[0], poly[k], poly[k + 1], sp[0], sp[k], sp[k + 1]);
+    for (int k = 1; k + 1 < n; ++k) raster_triangle(f, u, poly[0], poly[k], poly[k + 1], sp[0], sp[k], sp[k + 1], v);
 }
 
 /* generate_indices: render_buffer.rs:191-219 (vertex index = i*h + j <-> texel (x=i, y=j), :185-189) */

@@ -167,10 +167,8 @@ int emul_render(const EmulTile* tiles, uint32_t n_tiles, uint32_t tile_w, uint32
         float lin[4] = {0.0f, 0.71f, 0.885f, 1.0f};
         if (id != kNoTri) {
             const uint32_t draw = id >> 1, fan = id & 1u, rank = fastdiv(draw, div_tris), tri = draw - rank * tris_per_tile;
-            ResolvedTri r; float b[3];
-            if (!(resolve_vertices(td[rank], tile_w, div_hm1, tile_h - 1, view, W, H, tri, fan, ndec, r) && triangle_bary(r.s[0], r.s[1], r.s[2], px, py, b))) return -1;
             f3 wpos, wnrm;
-            interpolate(r.v[0], r.v[1], r.v[2], b, wpos, wnrm);
+            if (!resolve_varyings(td[rank], tile_w, div_hm1, tile_h - 1, view, W, H, tri, fan, ndec, px, py, wpos, wnrm)) return -1;
             shade_fragment(view.view_mode, {view.sun[0], view.sun[1], view.sun[2]}, view.cam_x, view.cam_y, (float)px + 0.5f,
                            (float)py + 0.5f, wpos, wnrm, lin);
         }

@@ -1030,12 +1030,8 @@ __global__ __launch_bounds__(256, TOPO_RESOLVE_WGS) void k_resolve(FrameParams P
             float lin[4] = {0.0f, 0.71f, 0.885f, 1.0f};
             const uint32_t draw = id >> 1, fan = id & 1u;
             const uint32_t rank = fastdiv(draw, P.div_tris), tri = draw - rank * P.tris_per_tile;
-            ResolvedTri r;
-            float b[3];
-            if (resolve_vertices(P.tiles[rank], P.tile_w, P.div_hm1, P.tile_h - 1, view, P.W, P.H, tri, fan, s_ndec, r) &&
-                triangle_bary(r.s[0], r.s[1], r.s[2], px, py, b)) {
-                f3 wpos, wnrm;
-                interpolate(r.v[0], r.v[1], r.v[2], b, wpos, wnrm);
+            f3 wpos, wnrm;
+            if (resolve_varyings(P.tiles[rank], P.tile_w, P.div_hm1, P.tile_h - 1, view, P.W, P.H, tri, fan, s_ndec, px, py, wpos, wnrm)) {
                 const f3 sun = {view.sun[0], view.sun[1], view.sun[2]};
                 shade_fragment(view.view_mode, sun, view.cam_x, view.cam_y, (float)px + 0.5f, (float)py + 0.5f, wpos, wnrm, lin);
             }

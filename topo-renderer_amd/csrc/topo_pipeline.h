@@ -290,9 +290,8 @@ TOPO_HD bool clip_near_fan(const VFull& v0, const VFull& v1, const VFull& v2, ui
 }
 
 // ---- perspective-correct varyings --------------------------------------------------------------------
-TOPO_HD void interpolate(const VFull& v0, const VFull& v1, const VFull& v2, const float b[3], f3& wpos, f3& wnrm) {
-    // q_i = b_i * (1/w_i); a = (a0*q0 + a1*q1 + a2*q2) * (1 / (q0+q1+q2)), sums as fma chains
-    const float q0 = b[0] * div_f(1.0f, v0.clip[3]), q1 = b[1] * div_f(1.0f, v1.clip[3]), q2 = b[2] * div_f(1.0f, v2.clip[3]);
+// a = (a0*q0 + a1*q1 + a2*q2) * (1 / (q0+q1+q2)), sums as fma chains
+TOPO_HD void interpolate_q(const VFull& v0, const VFull& v1, const VFull& v2, float q0, float q1, float q2, f3& wpos, f3& wnrm) {
     const float iq = div_f(1.0f, (q0 + q1) + q2);
     wpos.x = fmaf(v2.wpos.x, q2, fmaf(v1.wpos.x, q1, v0.wpos.x * q0)) * iq;
     wpos.y = fmaf(v2.wpos.y, q2, fmaf(v1.wpos.y, q1, v0.wpos.y * q0)) * iq;
@@ -300,6 +299,26 @@ TOPO_HD void interpolate(const VFull& v0, const VFull& v1, const VFull& v2, cons
     wnrm.x = fmaf(v2.wnrm.x, q2, fmaf(v1.wnrm.x, q1, v0.wnrm.x * q0)) * iq;
     wnrm.y = fmaf(v2.wnrm.y, q2, fmaf(v1.wnrm.y, q1, v0.wnrm.y * q0)) * iq;
     wnrm.z = fmaf(v2.wnrm.z, q2, fmaf(v1.wnrm.z, q1, v0.wnrm.z * q0)) * iq;
+}
+// Weights of an uncut triangle from its screen-space barycentrics: q_i = b_i * (1/w_i).
+TOPO_HD void interpolate(const VFull& v0, const VFull& v1, const VFull& v2, const float b[3], f3& wpos, f3& wnrm) {
+    interpolate_q(v0, v1, v2, b[0] * div_f(1.0f, v0.clip[3]), b[1] * div_f(1.0f, v1.clip[3]), b[2] * div_f(1.0f, v2.clip[3]), wpos, wnrm);
+}
+// Weights for a fragment of a primitive cut by the near plane (Raster spec 8): homogeneous barycentrics of the pixel
+// centre with respect to the primitive's own three vertices, q = adj([x y w]) . (gx, gy, 1) with (gx, gy) the centre in
+// normalised device coordinates.  Every product and difference is a separate rounding (no fma inside the 2x2
+// determinants); the three terms of a weight are one fma chain.
+TOPO_HD float det2(float a, float b, float c, float d) {
+    const float p = a * b, q = c * d;
+    return p - q;
+}
+TOPO_HD void homogeneous_weights(const VFull& v0, const VFull& v1, const VFull& v2, float W, float H, int32_t px, int32_t py, float q[3]) {
+    const float gx = fmaf((float)px + 0.5f, div_f(2.0f, W), -1.0f);
+    const float gy = fmaf(-((float)py + 0.5f), div_f(2.0f, H), 1.0f);
+    const float *c0 = v0.clip, *c1 = v1.clip, *c2 = v2.clip;
+    q[0] = fmaf(det2(c1[1], c2[3], c1[3], c2[1]), gx, fmaf(det2(c1[3], c2[0], c1[0], c2[3]), gy, det2(c1[0], c2[1], c1[1], c2[0])));
+    q[1] = fmaf(det2(c2[1], c0[3], c2[3], c0[1]), gx, fmaf(det2(c2[3], c0[0], c2[0], c0[3]), gy, det2(c2[0], c0[1], c2[1], c0[0])));
+    q[2] = fmaf(det2(c0[1], c1[3], c0[3], c1[1]), gx, fmaf(det2(c0[3], c1[0], c0[0], c1[3]), gy, det2(c0[0], c1[1], c0[1], c1[0])));
 }
 
 // Visibility-only version: clip position from the height alone.
@@ -315,8 +334,12 @@ struct ResolvedTri {
     SVert s[3];
     TriSetup ts;
 };
+// kShading (the resolve pass): a primitive cut by the near plane is not clipped -- its varyings come from its own three
+// vertices (homogeneous_weights) -- so the function returns false with `cut` set and r.v[] holding those vertices.
+// Without kShading (k_raster_rare: coverage and depth) the piece `fan` of the clipped polygon is produced.
+template <bool kShading = false>
 TOPO_HD bool resolve_vertices(const TileDev& t, uint32_t tile_w, FastDiv div_hm1, uint32_t hm1, const ViewDev& view, int32_t W, int32_t H,
-                              uint32_t tri, uint32_t fan, const float* ndec, ResolvedTri& r) {
+                              uint32_t tri, uint32_t fan, const float* ndec, ResolvedTri& r, bool* cut = nullptr) {
     // the triangle's three vertices are corners of one grid cell: two distinct longitudes, two distinct latitudes,
     // whose sin/cos pairs come from the tile's tables (same function of the same input as vertex_world)
     const uint32_t cell = tri >> 1, k = tri & 1u;
@@ -338,7 +361,10 @@ TOPO_HD bool resolve_vertices(const TileDev& t, uint32_t tile_w, FastDiv div_hm1
         mat4_point(view.proj, r.v[q].wpos.x, r.v[q].wpos.y, r.v[q].wpos.z, r.v[q].clip);
     }
     const bool all_in = r.v[0].clip[2] >= 0.0f && r.v[1].clip[2] >= 0.0f && r.v[2].clip[2] >= 0.0f;
-    if (!all_in) {   // near-plane clipping: replace the vertices by those of fan triangle `fan`
+    if (cut) *cut = !all_in;
+    if (kShading) {
+        if (!all_in) return false;
+    } else if (!all_in) {   // near-plane clipping: replace the vertices by those of fan triangle `fan`
         VFull a, b, c;
         if (!clip_near_fan(r.v[0], r.v[1], r.v[2], fan, a, b, c)) return false;
         r.v[0] = a; r.v[1] = b; r.v[2] = c;
@@ -353,7 +379,26 @@ TOPO_HD bool resolve_vertices(const TileDev& t, uint32_t tile_w, FastDiv div_hm1
 
 TOPO_HD bool resolve_triangle(const TileDev& t, uint32_t tile_w, FastDiv div_hm1, uint32_t hm1, const ViewDev& view, int32_t W,
                               int32_t H, uint32_t tri, uint32_t fan, ResolvedTri& r) {
-    return resolve_vertices(t, tile_w, div_hm1, hm1, view, W, H, tri, fan, nullptr, r) && triangle_setup(r.s[0], r.s[1], r.s[2], W, H, r.ts);
+    return resolve_vertices<false>(t, tile_w, div_hm1, hm1, view, W, H, tri, fan, nullptr, r) && triangle_setup(r.s[0], r.s[1], r.s[2], W, H, r.ts);
+}
+
+// Varyings of the fragment at pixel (px, py) whose winner is triangle `tri` (piece `fan`) of tile t: what fs_main receives.
+TOPO_HD bool resolve_varyings(const TileDev& t, uint32_t tile_w, FastDiv div_hm1, uint32_t hm1, const ViewDev& view, int32_t W, int32_t H,
+                              uint32_t tri, uint32_t fan, const float* ndec, int32_t px, int32_t py, f3& wpos, f3& wnrm) {
+    ResolvedTri r;
+    bool cut = false;
+    float q[3];
+    if (resolve_vertices<true>(t, tile_w, div_hm1, hm1, view, W, H, tri, fan, ndec, r, &cut)) {
+        float b[3];
+        if (fan != 0 || !triangle_bary(r.s[0], r.s[1], r.s[2], px, py, b)) return false;
+        q[0] = b[0] * div_f(1.0f, r.v[0].clip[3]); q[1] = b[1] * div_f(1.0f, r.v[1].clip[3]); q[2] = b[2] * div_f(1.0f, r.v[2].clip[3]);
+    } else if (cut) {
+        homogeneous_weights(r.v[0], r.v[1], r.v[2], (float)W, (float)H, px, py, q);
+    } else {
+        return false;
+    }
+    interpolate_q(r.v[0], r.v[1], r.v[2], q[0], q[1], q[2], wpos, wnrm);
+    return true;
 }
 
 // ---- peak visibility (render_engine.rs:338-396; glam Mat4::project_point3 + camera.rs:12-14) ---------------
