@@ -326,7 +326,7 @@ class TerrainRenderer:
         out = np.zeros(6, np.uint32)
         self._check(lib().topo_get_counters(self._h, _p(out)))
         return {"blocks_rastered": int(out[0]) + int(out[5]), "big_items": int(out[1]), "status": int(out[2]), "rare_items": int(out[3]),
-                "near_blocks": int(out[0]), "far_tested": int(out[4]), "far_survived": int(out[5])}
+                "near_blocks": int(out[0]), "far_tested": int(out[4]), "far_survived": int(out[5])}   # near/survivors: in 4-row strips
 
     def set_occlusion_split(self, metres: float):
         self._check(lib().topo_set_occlusion_split(self._h, metres))

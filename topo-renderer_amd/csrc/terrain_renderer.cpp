@@ -297,7 +297,7 @@ int TerrainRenderer::render_views_device(uint32_t n, const topo_uniforms* views,
     if (int rc = ensure(&d_views_, &cap_views_, sizeof(ViewDev) * kMaxViewsPerSlot * kViewSlots)) return rc;
     const size_t near_cap = 8 * work_cap;   // a near block is cut into strips of >= 2 cell rows: at most 8
     if (int rc = ensure(&d_work_, &cap_work_, (near_cap ? near_cap : 1) * sizeof(WorkItem))) return rc;
-    if (int rc = ensure(&d_work2_, &cap_work2_, (work_cap ? work_cap : 1) * sizeof(WorkItem))) return rc;
+    if (int rc = ensure(&d_work2_, &cap_work2_, (near_cap ? near_cap : 1) * sizeof(WorkItem))) return rc;   // far survivors, in strips too
     if (int rc = ensure(&d_far_, &cap_far_, (work_cap ? work_cap : 1) * sizeof(FarItem))) return rc;
     if (int rc = ensure(&d_big_, &cap_big_, big_cap * sizeof(BigItem))) return rc;
     if (int rc = ensure(&d_rare_, &cap_rare_, rare_cap * sizeof(RareItem))) return rc;

@@ -403,8 +403,15 @@ __global__ __launch_bounds__(256) void k_occlusion(FrameParams P) {
             }
         }
         if (visible && lane == 0) {
-            const uint32_t slot = atomicAdd(&P.counters[5], 1u);
-            if (slot < P.work_cap) P.work2[slot] = WorkItem{fi.view_rank, fi.block};
+            // survivors are few: cut them into strips like the near blocks, or the second raster phase runs on a
+            // fraction of the resident waves
+            const uint32_t blk = fi.block, by = blk / P.bx_count;
+            const uint32_t cell_rows = min(kBCY, P.tile_h - 1 - by * kBCY);
+            const uint32_t n = (cell_rows + kStrip - 1) / kStrip;
+            const uint32_t base = atomicAdd(&P.counters[5], n);
+            for (uint32_t k = 0; k < n; ++k)
+                if (base + k < P.near_cap)
+                    P.work2[base + k] = WorkItem{fi.view_rank, blk | ((kStrip * k) << 24) | (min(kStrip, cell_rows - kStrip * k) << 28)};
         }
     }
 }
@@ -652,7 +659,7 @@ __global__ __launch_bounds__(256, TOPO_RASTER_WAVES) void k_raster(FrameParams P
     __shared__ TriList s_tl[4];
     const WorkItem* __restrict__ work = phase == 0 ? P.work : P.work2;
     uint32_t count = P.counters[phase == 0 ? 0 : 5];
-    const uint32_t cap = phase == 0 ? P.near_cap : P.work_cap;
+    const uint32_t cap = P.near_cap;      // both lists hold strips
     if (count > cap) count = cap;
     // the wave index is wave-uniform: say so (readfirstlane), or the compiler treats everything derived from the
     // work item -- the view matrix, the tile descriptor -- as per-lane data and re-loads it with vector loads.
