@@ -51,6 +51,10 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--check", action="store_true", help="verify sector 0 against the oracle (slow)")
     ap.add_argument("--occlusion-split", type=float, default=None, help="metres; 0 disables the two-phase occlusion filter")
+    ap.add_argument("--pipeline", type=int, default=None,
+                    help="frames in flight (topo_set_pipeline_depth) in the timed region; default 1 = strictly one panorama "
+                         "after the other (per-kernel durations are then those of the kernel alone); at N=1 a second, "
+                         "untimed-for-`value` pass with 2 frames in flight is reported under \"pipelined\"")
     ap.add_argument("--pitch", type=float, default=0.0, help="camera pitch in radians (reference: positive looks down)")
     ap.add_argument("--host-path", action="store_true", help="also time topo_render (host outputs, PCIe-inclusive)")
     args = ap.parse_args()
@@ -91,6 +95,7 @@ def main():
     r.set_stream(torch.cuda.current_stream().cuda_stream)
     if args.occlusion_split is not None:
         r.set_occlusion_split(args.occlusion_split)
+    depth_frames = args.pipeline if args.pipeline is not None else 1
     vlat, vlon = LAT0 + deg / 2 + 0.123, LON0 + deg / 2 + 0.217      # mosaic centre + (0.123, 0.217) degrees
     ground = None
     upload_s = 0.0
@@ -119,12 +124,19 @@ def main():
     # contiguous block and can run while slot c+1 is being rendered
     per = N_SECTORS // world
     my = list(T.panorama.sector_range(rank, world))
-    strip = torch.empty(T.panorama.strip_shape(world, PH, SW), dtype=torch.uint8, device="cuda")
-    depth = torch.empty((per, PH, SW), dtype=torch.float32, device="cuda")
+    # one output set per frame in flight
+    r.set_pipeline_depth(depth_frames)
+    outs = [(torch.empty(T.panorama.strip_shape(world, PH, SW), dtype=torch.uint8, device="cuda"),
+             torch.empty((per, PH, SW), dtype=torch.float32, device="cuda")) for _ in range(depth_frames)]
+    strip, depth = outs[0]
+    frame_no = [0]
 
     def step():
+        nonlocal strip, depth
         if world == 1:
             # one submission for all 8 sectors: strip[c][0] are contiguous
+            strip, depth = outs[frame_no[0] % depth_frames]
+            frame_no[0] += 1
             r.render_views_device(views, SW, PH, strip.data_ptr(), PH * SW * 4, SW * 4, depth.data_ptr(), PH * SW * 4, SW * 4)
             return
         works = []
@@ -136,6 +148,7 @@ def main():
             w.wait()
 
     def fence():
+        r.join()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -144,14 +157,18 @@ def main():
         step()
     fence()
     kernel_ms = {k: 0.0 for k in ("clear", "cull", "raster", "occlusion", "raster_big", "resolve", "total")}
+    timed_frames = 0
     t_start = time.perf_counter()
     for _ in range(args.steps):
         step()
-        # HIP-event durations of this step's kernels (events sit on the same stream; reading them waits for
-        # the step, which the timed loop does anyway before the next submission's host-side staging)
+        # HIP-event durations of a step's kernels (the events sit on the stream the kernels are launched on).  One frame in
+        # flight: this step's (reading them waits for it, which the next submission's host-side staging does anyway);
+        # pipelined: those of the oldest frame in flight, so that reading them does not drain the pipeline
         tm = r.timings()                 # N > 1: the last sector submission of the step
-        for k in kernel_ms:
-            kernel_ms[k] += tm[k] * (per if world > 1 else 1)
+        if tm["total"] > 0.0:
+            timed_frames += 1
+            for k in kernel_ms:
+                kernel_ms[k] += tm[k] * (per if world > 1 else 1)
     fence()
     elapsed = time.perf_counter() - t_start
     if dist is not None:
@@ -160,7 +177,7 @@ def main():
         elapsed = float(tt.item())
     ms_per_step = 1e3 * elapsed / args.steps
     for k in kernel_ms:
-        kernel_ms[k] /= args.steps
+        kernel_ms[k] /= max(1, timed_frames)
     counters = r.counters()
 
     mpix = PW * PH / 1e6
@@ -217,6 +234,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"{args.workload}: {deg}x{deg} deg COP90-shaped mosaic ({n_tiles} tiles of 1200x1200 f32), "
                                f"{PW}x{PH} panorama = 8 sectors of {SW}x{PH}, view_mode {args.view_mode}",
+                   "frames_in_flight": depth_frames,
                    "sharding": f"azimuth sectors, {per} per GPU, DEM replicated" + (", RCCL all-gather of RGBA per sector slot, pipelined with rendering" if world > 1 else "")},
         "roofline": roofline,
         "per_kernel": per_kernel,
@@ -229,6 +247,27 @@ def main():
         "setup_s": round(setup_s, 1),
         "upload_s": round(upload_s, 2),
     }
+
+    # ---- throughput mode (additive, never `value`): consecutive panoramas with two frames in flight, so that the
+    # latency-bound cull/raster phases of one run under the ALU-bound resolve of the previous one
+    if world == 1 and args.pipeline is None:
+        r.set_pipeline_depth(2)
+        outs2 = outs + [(torch.empty_like(outs[0][0]), torch.empty_like(outs[0][1]))]
+        def step2(i):
+            s2, d2 = outs2[i % 2]
+            r.render_views_device(views, SW, PH, s2.data_ptr(), PH * SW * 4, SW * 4, d2.data_ptr(), PH * SW * 4, SW * 4)
+        for i in range(max(2, args.warmup)):
+            step2(i)
+        fence()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            step2(i)
+        fence()
+        dt = (time.perf_counter() - t1) / args.steps
+        out["pipelined"] = {"frames_in_flight": 2, "ms_per_step": round(dt * 1e3, 4), "value": round(mpix / dt, 2), "unit": "Mpix/s",
+                            "what": "the same panoramas back to back with topo_set_pipeline_depth(2); kernels of adjacent frames overlap"}
+        r.set_pipeline_depth(1)
+        del outs2
 
     # ---- CPU baseline: the oracle (a C++ port of the reference's shaders + raster semantics; the reference's
     # own wgpu CPU-adapter path cannot be built here) on a bounded sample, rank 0 at N=1 only.
@@ -285,14 +324,19 @@ def bench_batch(args, T, np, torch, dist, r, locs, deg, SW, PH, rank, world, set
     per = C5_VIEWPOINTS // world
     mine = vps[rank * per:(rank + 1) * per]
     sets = [T.panorama_uniforms(e, yaw, SW, PH, lon, lat, args.view_mode) for (e, yaw, lon, lat) in mine]
-    strip = torch.empty((N_SECTORS, PH, SW, 4), dtype=torch.uint8, device="cuda")
-    depth = torch.empty((N_SECTORS, PH, SW), dtype=torch.float32, device="cuda")
+    # throughput mode: independent viewpoints, so several frames are kept in flight (one output set each)
+    in_flight = args.pipeline if args.pipeline is not None else 3
+    r.set_pipeline_depth(in_flight)
+    outs = [(torch.empty((N_SECTORS, PH, SW, 4), dtype=torch.uint8, device="cuda"),
+             torch.empty((N_SECTORS, PH, SW), dtype=torch.float32, device="cuda")) for _ in range(in_flight)]
 
     def step():      # one step = this rank's whole share of the batch
-        for vs in sets:
+        for i, vs in enumerate(sets):
+            strip, depth = outs[i % in_flight]
             r.render_views_device(vs, SW, PH, strip.data_ptr(), PH * SW * 4, SW * 4, depth.data_ptr(), PH * SW * 4, SW * 4)
 
     def fence():
+        r.join()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -315,6 +359,7 @@ def bench_batch(args, T, np, torch, dist, r, locs, deg, SW, PH, rank, world, set
            "n_gpus": world, "steps": steps, "warmup": min(args.warmup, 1), "ms_per_step": round(ms, 3), "higher_is_better": True,
            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"c5: batch of {C5_VIEWPOINTS} viewpoints over the {deg}x{deg} deg mosaic, {N_SECTORS * SW}x{PH} panorama each",
+                      "frames_in_flight": in_flight,
                       "sharding": f"viewpoints, {per} per GPU, DEM replicated, no collective"},
            "ms_per_viewpoint": round(ms / per, 4), "setup_s": round(setup_s, 1)}
     if rank == 0:

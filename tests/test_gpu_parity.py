@@ -454,3 +454,55 @@ def test_frame_sequence_on_one_renderer(topo, orc):
         g.update(W, H, u, pu)
         o.update(W, H, u, pu)
         assert_same_frame(g.render(), o.render(), "sequence: single frame after a panorama")
+
+
+def test_pipelined_frames_equal_serial_frames(topo, orc):
+    """topo_set_pipeline_depth: frames kept in flight on their own streams give the bytes the one-at-a-time path gives
+    (and the oracle's), also across tile changes and a switch back to depth 1."""
+    import torch
+    sc = Scene(64, 2, 2, eye_dh=60)
+    g, o = both(topo, orc, 96, 64)
+    sc.load(g)
+    sc.load(o)
+    W, H = 96, 64
+    pans = [sc.panorama(W, H, yaw0_deg=y) for y in (0, 33, 170, 285, 90, 201)]
+    bufs = [(torch.empty((8, H, W, 4), dtype=torch.uint8, device="cuda"), torch.empty((8, H, W), dtype=torch.float32, device="cuda"))
+            for _ in pans]
+
+    def check(k_list=(0, 5)):
+        for views, (s, d) in zip(pans, bufs):
+            for k in k_list:
+                o.update(W, H, views[k], topo.post_uniforms(W, H))
+                assert_same_frame((s[k].cpu().numpy(), d[k].cpu().numpy()), o.render(), "pipelined panorama")
+
+    for depth in (3, 2, 1):
+        g.set_pipeline_depth(depth)
+        for b in bufs:
+            b[0].zero_()
+            b[1].zero_()
+        torch.cuda.synchronize()
+        for views, (s, d) in zip(pans, bufs):
+            g.render_views_device(views, W, H, s.data_ptr(), H * W * 4, W * 4, d.data_ptr(), H * W * 4, W * 4)
+        g.join()
+        torch.cuda.synchronize()
+        check()
+    # tiles change while frames are in flight: add/unload join the pipeline first
+    g.set_pipeline_depth(2)
+    for views, (s, d) in zip(pans[:3], bufs[:3]):
+        g.render_views_device(views, W, H, s.data_ptr(), H * W * 4, W * 4, d.data_ptr(), H * W * 4, W * 4)
+    g.unload_terrain(*sc.locs[1])
+    o.unload_terrain(*sc.locs[1])
+    for views, (s, d) in zip(pans[3:], bufs[3:]):
+        g.render_views_device(views, W, H, s.data_ptr(), H * W * 4, W * 4, d.data_ptr(), H * W * 4, W * 4)
+    g.join()
+    torch.cuda.synchronize()
+    for views, (s, d) in zip(pans[3:], bufs[3:]):
+        o.update(W, H, views[2], topo.post_uniforms(W, H))
+        assert_same_frame((s[2].cpu().numpy(), d[2].cpu().numpy()), o.render(), "pipelined panorama after unload")
+    # the host path still returns a finished frame
+    u, pu = sc.uniforms(W, H, 20, 10, 70, 0), topo.post_uniforms(W, H)
+    g.update(W, H, u, pu)
+    o.update(W, H, u, pu)
+    assert_same_frame(g.render(), o.render(), "topo_render with a pipeline depth of 2")
+    with pytest.raises(topo.TopoError):
+        g.set_pipeline_depth(9)

@@ -96,6 +96,8 @@ def lib():
             "topo_read_normals": (C.c_int, [vp, i32, i32, vp]),
             "topo_probe_sincos": (C.c_int, [vp, vp, vp, vp, sz]),
             "topo_probe_div": (C.c_int, [vp, i32, vp, vp, vp, sz]),
+            "topo_set_pipeline_depth": (C.c_int, [vp, i32]),
+            "topo_join": (C.c_int, [vp]),
             "topo_visible_peaks": (C.c_int, [vp, u32, vp, vp, vp]),
             "topo_visible_peaks_device": (C.c_int, [vp, vp, u32, u32, vp, sz, u32, vp, vp, vp]),
             "topo_camera_uniforms": (None, [vp, f32, f32, f32, f32, f32, f32, f32, i32, vp]),
@@ -307,6 +309,13 @@ class TerrainRenderer:
 
     def set_stream(self, hip_stream: int):
         self._check(lib().topo_set_stream(self._h, C.c_void_p(hip_stream) if hip_stream else None))
+
+    def set_pipeline_depth(self, depth: int):
+        """Frames in flight for render_views_device (topo_set_pipeline_depth); outputs are complete after join()."""
+        self._check(lib().topo_set_pipeline_depth(self._h, depth))
+
+    def join(self):
+        self._check(lib().topo_join(self._h))
 
     def synchronize(self):
         self._check(lib().topo_synchronize(self._h))

@@ -48,7 +48,9 @@ int TerrainRenderer::create(TerrainRenderer** out, int device, uint32_t w, uint3
     r->H_ = h;
     e = hipSetDevice(device);
     if (e == hipSuccess) e = hipStreamCreate(&r->own_stream_);
-    for (int i = 0; i < kNumEvents && e == hipSuccess; ++i) e = hipEventCreate(&r->ev_[i]);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreate(&r->load_ev_[i]);
+    for (int i = 0; i < kNumEvents && e == hipSuccess; ++i) e = hipEventCreate(&r->ctx_[0].ev[i]);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&r->ctx_[0].done, hipEventDisableTiming);
     if (e != hipSuccess) {
         *err = std::string("HIP initialisation failed: ") + hipGetErrorString(e);
         delete r;
@@ -62,16 +64,26 @@ int TerrainRenderer::create(TerrainRenderer** out, int device, uint32_t w, uint3
 TerrainRenderer::~TerrainRenderer() {
     (void)hipSetDevice(device_);
     if (stream_) (void)hipStreamSynchronize(stream_);
+    for (auto& c : ctx_)
+        if (c.stream) (void)hipStreamSynchronize(c.stream);
     for (auto& kv : tiles_) {
         (void)hipFree(kv.second.d_heights);
         (void)hipFree(kv.second.d_normals);
         (void)hipFree(kv.second.d_minmax);
     }
-    void* bufs[] = {d_tiles_, d_views_, d_vis_, d_dirty_, d_work_, d_work2_, d_far_, d_big_, d_rare_, d_counters_, d_out_rgba_, d_out_depth_,
-                    d_edge_jobs_, d_corner_jobs_, d_peaks_, d_proj_};
+    void* bufs[] = {d_tiles_, d_views_, d_out_rgba_, d_out_depth_, d_edge_jobs_, d_corner_jobs_, d_peaks_, d_proj_};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
-    for (auto& e : ev_)
+    for (auto& c : ctx_) {
+        void* cb[] = {c.d_vis, c.d_dirty, c.d_work, c.d_work2, c.d_far, c.d_big, c.d_rare, c.d_counters};
+        for (void* p : cb)
+            if (p) (void)hipFree(p);
+        for (auto& e : c.ev)
+            if (e) (void)hipEventDestroy(e);
+        if (c.done) (void)hipEventDestroy(c.done);
+        if (c.stream) (void)hipStreamDestroy(c.stream);
+    }
+    for (auto& e : load_ev_)
         if (e) (void)hipEventDestroy(e);
     for (auto& e : view_ev_)
         if (e) (void)hipEventDestroy(e);
@@ -79,10 +91,12 @@ TerrainRenderer::~TerrainRenderer() {
     if (own_stream_) (void)hipStreamDestroy(own_stream_);
 }
 
-int TerrainRenderer::ensure(void** p, size_t* cap, size_t need) {
+int TerrainRenderer::ensure(void** p, size_t* cap, size_t need) { return ensure_on(stream_, p, cap, need); }
+
+int TerrainRenderer::ensure_on(hipStream_t s, void** p, size_t* cap, size_t need) {
     if (need <= *cap) return TOPO_OK;
     if (*p) {
-        TOPO_HIP_TRY(hipStreamSynchronize(stream_));
+        TOPO_HIP_TRY(hipStreamSynchronize(s));
         TOPO_HIP_TRY(hipFree(*p));
         *p = nullptr;
         *cap = 0;
@@ -155,7 +169,7 @@ int TerrainRenderer::add_terrain(int32_t lat, int32_t lon, const float* heights,
     if (w > 32768 || h > 32768) return fail(TOPO_ERR_INVALID, "tile too large");
     if (!tiles_.empty() && (w != tile_w_ || h != tile_h_))
         return fail(TOPO_ERR_INVALID, "mixed tile sizes are rejected (the reference caches one mesh: render_buffer.rs:12-15)");
-    if (int rc = bind_device()) return rc;
+    if (int rc = join()) return rc;
     const uint64_t tris = 2ull * (w - 1) * (h - 1);
     const size_t n_after = tiles_.size() + (find(lat, lon) ? 0 : 1);
     if (tris * n_after >= (1ull << 31) || n_after > 0xFFFFu) return fail(TOPO_ERR_CAPACITY, "draw-order id space exhausted");
@@ -218,7 +232,7 @@ int TerrainRenderer::add_terrain(int32_t lat, int32_t lon, const float* heights,
 int TerrainRenderer::unload_terrain(int32_t lat, int32_t lon) {
     Tile* t = find(lat, lon);
     if (!t) return TOPO_OK;   // BTreeMap::remove of a missing key is a no-op
-    if (int rc = bind_device()) return rc;
+    if (int rc = join()) return rc;
     TOPO_HIP_TRY(hipStreamSynchronize(stream_));
     (void)hipFree(t->d_heights); (void)hipFree(t->d_normals); (void)hipFree(t->d_minmax);
     tiles_.erase(geo_key(lat, lon));
@@ -227,7 +241,7 @@ int TerrainRenderer::unload_terrain(int32_t lat, int32_t lon) {
 }
 
 int TerrainRenderer::recompute_normals() {
-    if (int rc = bind_device()) return rc;
+    if (int rc = join()) return rc;
     std::vector<Tile*> order;
     for (auto& kv : tiles_) order.push_back(&kv.second);
     std::sort(order.begin(), order.end(), [](Tile* a, Tile* b) { return a->seq < b->seq; });
@@ -238,10 +252,10 @@ int TerrainRenderer::recompute_normals() {
     for (Tile* t : order) collect_jobs(*t, rk, edges, corners);
     if (int rc = ensure(&d_edge_jobs_, &cap_edge_jobs_, (edges.size() + 1) * sizeof(EdgeJob))) return rc;
     if (int rc = ensure(&d_corner_jobs_, &cap_corner_jobs_, (corners.size() + 1) * sizeof(CornerJob))) return rc;
-    TOPO_HIP_TRY(hipEventRecord(ev_[9], stream_));
+    TOPO_HIP_TRY(hipEventRecord(load_ev_[0], stream_));
     launch_normals_interior((const TileDev*)d_tiles_, 0, (uint32_t)order.size(), tile_w_, tile_h_, lds_rows_, stream_);
     if (int rc = run_seam_jobs(edges, corners)) return rc;
-    TOPO_HIP_TRY(hipEventRecord(ev_[10], stream_));
+    TOPO_HIP_TRY(hipEventRecord(load_ev_[1], stream_));
     TOPO_HIP_TRY(hipStreamSynchronize(stream_));   // the job lists are locals
     load_timed_ = true;
     TOPO_HIP_TRY(hipGetLastError());
@@ -274,12 +288,59 @@ int TerrainRenderer::upload_tile_table() {
     return TOPO_OK;
 }
 
+int TerrainRenderer::init_ctx(FrameCtx& c, bool own_stream) {
+    if (!c.done) {
+        for (auto& e : c.ev) TOPO_HIP_TRY(hipEventCreate(&e));
+        TOPO_HIP_TRY(hipEventCreateWithFlags(&c.done, hipEventDisableTiming));
+    }
+    if (own_stream && !c.stream) TOPO_HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    return TOPO_OK;
+}
+
+// Frames in flight on the contexts' own streams are not ordered with stream_: everything that frees or rewrites what a
+// frame reads (tiles, the tile table), and every consumer of a frame's outputs, joins them first.
+int TerrainRenderer::join() {
+    if (int rc = bind_device()) return rc;
+    for (auto& c : ctx_)
+        if (c.pending && c.stream) {
+            TOPO_HIP_TRY(hipStreamSynchronize(c.stream));
+            c.pending = false;
+        }
+    return TOPO_OK;
+}
+
+int TerrainRenderer::set_pipeline_depth(int depth) {
+    if (depth < 1 || depth > kMaxPipeline) return fail(TOPO_ERR_INVALID, "pipeline depth must be 1..4");
+    if (int rc = join()) return rc;
+    TOPO_HIP_TRY(hipStreamSynchronize(stream_));
+    for (int i = 0; i < depth; ++i)
+        if (int rc = init_ctx(ctx_[i], depth > 1)) return rc;
+    pipeline_depth_ = depth;
+    next_ctx_ = last_ctx_ = 0;
+    return TOPO_OK;
+}
+
 int TerrainRenderer::render_views_device(uint32_t n, const topo_uniforms* views, uint32_t w, uint32_t h, const OutputParams& out) {
     if (n == 0 || !views || !out.rgba) return fail(TOPO_ERR_INVALID, "null/empty argument");
     if (n > 0xFFFFu) return fail(TOPO_ERR_INVALID, "too many views");
     if (w == 0 || h == 0 || w > 65536 || h > 65536) return fail(TOPO_ERR_INVALID, "bad target size");
     if (int rc = bind_device()) return rc;
+    if (table_dirty_)
+        if (int rc = join()) return rc;
     if (int rc = upload_tile_table()) return rc;
+    FrameCtx& c = ctx_[next_ctx_];
+    last_ctx_ = next_ctx_;
+    next_ctx_ = (next_ctx_ + 1) % pipeline_depth_;
+    if (pipeline_depth_ == 1) return render_frame(c, stream_, n, views, w, h, out);
+    // the tile table (and whatever else the caller queued) was produced on stream_: order the frame after it
+    TOPO_HIP_TRY(hipEventRecord(c.done, stream_));
+    TOPO_HIP_TRY(hipStreamWaitEvent(c.stream, c.done, 0));
+    c.pending = true;
+    return render_frame(c, c.stream, n, views, w, h, out);
+}
+
+int TerrainRenderer::render_frame(FrameCtx& c, hipStream_t stream, uint32_t n, const topo_uniforms* views, uint32_t w, uint32_t h,
+                                  const OutputParams& out) {
     const uint32_t n_tiles = (uint32_t)tiles_.size();
     const uint32_t bxc = n_tiles ? (tile_w_ - 1 + kBCX - 1) / kBCX : 0, byc = n_tiles ? (tile_h_ - 1 + kBCY - 1) / kBCY : 0;
     const size_t pixels = (size_t)n * w * h;
@@ -288,22 +349,22 @@ int TerrainRenderer::render_views_device(uint32_t n, const topo_uniforms* views,
     if (work_cap >= (1ull << 30)) return fail(TOPO_ERR_CAPACITY, "too many raster blocks in one submission");
     if (pixels >= (1ull << 32)) return fail(TOPO_ERR_CAPACITY, "more than 2^32 pixels in one submission");
     const size_t vis_keys = (pixels + 63) & ~(size_t)63;   // whole 64-key segments: k_clear rewrites segments, not keys
-    if (vis_keys * 8 > cap_vis_) {
+    if (vis_keys * 8 > c.cap_vis) {
         // a fresh buffer holds garbage: mark every segment so that the first k_clear initialises all of it
-        if (int rc = ensure(&d_vis_, &cap_vis_, vis_keys * 8)) return rc;
-        if (int rc = ensure(&d_dirty_, &cap_dirty_, vis_keys / 64 + 64)) return rc;
-        TOPO_HIP_TRY(hipMemsetAsync(d_dirty_, 1, cap_dirty_, stream_));
+        if (int rc = ensure_on(stream, &c.d_vis, &c.cap_vis, vis_keys * 8)) return rc;
+        if (int rc = ensure_on(stream, &c.d_dirty, &c.cap_dirty, vis_keys / 64 + 64)) return rc;
+        TOPO_HIP_TRY(hipMemsetAsync(c.d_dirty, 1, c.cap_dirty, stream));
     }
     if (int rc = ensure(&d_views_, &cap_views_, sizeof(ViewDev) * kMaxViewsPerSlot * kViewSlots)) return rc;
     const size_t near_cap = 8 * work_cap;   // a near block is cut into strips of >= 2 cell rows: at most 8
-    if (int rc = ensure(&d_work_, &cap_work_, (near_cap ? near_cap : 1) * sizeof(WorkItem))) return rc;
-    if (int rc = ensure(&d_work2_, &cap_work2_, (near_cap ? near_cap : 1) * sizeof(WorkItem))) return rc;   // far survivors, in strips too
-    if (int rc = ensure(&d_far_, &cap_far_, (work_cap ? work_cap : 1) * sizeof(FarItem))) return rc;
-    if (int rc = ensure(&d_big_, &cap_big_, big_cap * sizeof(BigItem))) return rc;
-    if (int rc = ensure(&d_rare_, &cap_rare_, rare_cap * sizeof(RareItem))) return rc;
-    if (!d_counters_) {
-        if (int rc = ensure(&d_counters_, &cap_counters_, 16 * sizeof(uint32_t))) return rc;
-        TOPO_HIP_TRY(hipMemsetAsync(d_counters_, 0, 16 * sizeof(uint32_t), stream_));
+    if (int rc = ensure_on(stream, &c.d_work, &c.cap_work, (near_cap ? near_cap : 1) * sizeof(WorkItem))) return rc;
+    if (int rc = ensure_on(stream, &c.d_work2, &c.cap_work2, (near_cap ? near_cap : 1) * sizeof(WorkItem))) return rc;   // far survivors, in strips too
+    if (int rc = ensure_on(stream, &c.d_far, &c.cap_far, (work_cap ? work_cap : 1) * sizeof(FarItem))) return rc;
+    if (int rc = ensure_on(stream, &c.d_big, &c.cap_big, big_cap * sizeof(BigItem))) return rc;
+    if (int rc = ensure_on(stream, &c.d_rare, &c.cap_rare, rare_cap * sizeof(RareItem))) return rc;
+    if (!c.d_counters) {
+        if (int rc = ensure_on(stream, &c.d_counters, &c.cap_counters, 16 * sizeof(uint32_t))) return rc;
+        TOPO_HIP_TRY(hipMemsetAsync(c.d_counters, 0, 16 * sizeof(uint32_t), stream));
     }
     // view constants go through a small ring of pinned staging slots, each guarded by an event, so a submission
     // never has to wait for the stream (pageable sources would force a synchronous staging copy)
@@ -325,21 +386,21 @@ int TerrainRenderer::render_views_device(uint32_t n, const topo_uniforms* views,
     }
     // each slot has its own device copy, so a later submission cannot overwrite constants a running frame reads
     ViewDev* d_slot = (ViewDev*)d_views_ + (size_t)slot * kMaxViewsPerSlot;
-    TOPO_HIP_TRY(hipMemcpyAsync(d_slot, vd, n * sizeof(ViewDev), hipMemcpyHostToDevice, stream_));
-    TOPO_HIP_TRY(hipEventRecord(view_ev_[slot], stream_));
+    TOPO_HIP_TRY(hipMemcpyAsync(d_slot, vd, n * sizeof(ViewDev), hipMemcpyHostToDevice, stream));
+    TOPO_HIP_TRY(hipEventRecord(view_ev_[slot], stream));
     view_used_[slot] = true;
 
     FrameParams p{};
     p.tiles = (const TileDev*)d_tiles_;
     p.views = d_slot;
-    p.vis = (uint64_t*)d_vis_;
-    p.dirty = (uint8_t*)d_dirty_;
-    p.work = (WorkItem*)d_work_;
-    p.counters = (uint32_t*)d_counters_;
-    p.big = (BigItem*)d_big_;
-    p.rare = (RareItem*)d_rare_;
-    p.far = (FarItem*)d_far_;
-    p.work2 = (WorkItem*)d_work2_;
+    p.vis = (uint64_t*)c.d_vis;
+    p.dirty = (uint8_t*)c.d_dirty;
+    p.work = (WorkItem*)c.d_work;
+    p.counters = (uint32_t*)c.d_counters;
+    p.big = (BigItem*)c.d_big;
+    p.rare = (RareItem*)c.d_rare;
+    p.far = (FarItem*)c.d_far;
+    p.work2 = (WorkItem*)c.d_work2;
     p.split_m = occlusion_split_m_;
     p.rare_cap = (uint32_t)rare_cap;
     p.work_cap = (uint32_t)work_cap;
@@ -367,31 +428,31 @@ int TerrainRenderer::render_views_device(uint32_t n, const topo_uniforms* views,
     // clear -> cull -> [near blocks: raster, rare, big] -> occlusion test of the far blocks -> [survivors: raster,
     // rare, big] -> resolve.  Event slots: 0 clear, 1 cull, 2 raster(near), 3 rare+big(near), 4 occlusion,
     // 5 raster(far), 6 rare+big(far), 7 resolve.
-    TOPO_HIP_TRY(hipEventRecord(ev_[0], stream_));
-    launch_clear(p, stream_);
-    TOPO_HIP_TRY(hipEventRecord(ev_[1], stream_));
-    launch_cull(p, stream_);
-    TOPO_HIP_TRY(hipEventRecord(ev_[2], stream_));
-    launch_raster(p, 0, stream_);
-    TOPO_HIP_TRY(hipEventRecord(ev_[3], stream_));
-    launch_raster_rare(p, stream_);
-    launch_raster_big(p, stream_);
-    TOPO_HIP_TRY(hipEventRecord(ev_[4], stream_));
+    TOPO_HIP_TRY(hipEventRecord(c.ev[0], stream));
+    launch_clear(p, stream);
+    TOPO_HIP_TRY(hipEventRecord(c.ev[1], stream));
+    launch_cull(p, stream);
+    TOPO_HIP_TRY(hipEventRecord(c.ev[2], stream));
+    launch_raster(p, 0, stream);
+    TOPO_HIP_TRY(hipEventRecord(c.ev[3], stream));
+    launch_raster_rare(p, stream);
+    launch_raster_big(p, stream);
+    TOPO_HIP_TRY(hipEventRecord(c.ev[4], stream));
     if (p.split_m > 0.0f) {
-        launch_phase_mark(p, stream_);
-        launch_occlusion(p, stream_);
+        launch_phase_mark(p, stream);
+        launch_occlusion(p, stream);
     }
-    TOPO_HIP_TRY(hipEventRecord(ev_[5], stream_));
-    if (p.split_m > 0.0f) launch_raster(p, 1, stream_);
-    TOPO_HIP_TRY(hipEventRecord(ev_[6], stream_));
+    TOPO_HIP_TRY(hipEventRecord(c.ev[5], stream));
+    if (p.split_m > 0.0f) launch_raster(p, 1, stream);
+    TOPO_HIP_TRY(hipEventRecord(c.ev[6], stream));
     if (p.split_m > 0.0f) {
-        launch_raster_rare(p, stream_);
-        launch_raster_big(p, stream_);
+        launch_raster_rare(p, stream);
+        launch_raster_big(p, stream);
     }
-    TOPO_HIP_TRY(hipEventRecord(ev_[7], stream_));
-    launch_resolve(p, out, stream_);
-    TOPO_HIP_TRY(hipEventRecord(ev_[8], stream_));
-    frame_timed_ = true;
+    TOPO_HIP_TRY(hipEventRecord(c.ev[7], stream));
+    launch_resolve(p, out, stream);
+    TOPO_HIP_TRY(hipEventRecord(c.ev[8], stream));
+    c.timed = true;
     TOPO_HIP_TRY(hipGetLastError());
     return TOPO_OK;
 }
@@ -414,6 +475,8 @@ int TerrainRenderer::render(uint8_t* rgba, size_t rgba_pitch, float* depth, size
     o.depth_view_stride = row * H_;
     o.depth_pitch = row;
     if (int rc = render_views_device(1, &uniforms_, W_, H_, o)) return rc;
+    if (int rc = join()) return rc;       // (pipelined contexts run on their own streams)
+    void* d_counters_ = ctx_[last_ctx_].d_counters;
     TOPO_HIP_TRY(hipMemcpy2DAsync(rgba, rgba_pitch, d_out_rgba_, row, row, H_, hipMemcpyDeviceToHost, stream_));
     if (depth) TOPO_HIP_TRY(hipMemcpy2DAsync(depth, depth_pitch, d_out_depth_, row, row, H_, hipMemcpyDeviceToHost, stream_));
     TOPO_HIP_TRY(hipStreamSynchronize(stream_));
@@ -458,14 +521,14 @@ int TerrainRenderer::visible_peaks(uint32_t n, const float* peaks, uint8_t* visi
 }
 
 int TerrainRenderer::set_stream(hipStream_t s) {
-    if (int rc = bind_device()) return rc;
+    if (int rc = join()) return rc;
     TOPO_HIP_TRY(hipStreamSynchronize(stream_));
     stream_ = s ? s : own_stream_;
     return TOPO_OK;
 }
 
 int TerrainRenderer::synchronize() {
-    if (int rc = bind_device()) return rc;
+    if (int rc = join()) return rc;
     TOPO_HIP_TRY(hipStreamSynchronize(stream_));
     return TOPO_OK;
 }
@@ -485,17 +548,21 @@ int TerrainRenderer::set_occlusion_split(float metres) {
 int TerrainRenderer::set_queue_caps(uint32_t big_cap, uint32_t rare_cap) {
     big_cap_cfg_ = big_cap;
     rare_cap_cfg_ = rare_cap;
-    if (d_counters_) {   // the status bits are sticky across frames: a new configuration starts clean
-        if (int rc = bind_device()) return rc;
-        TOPO_HIP_TRY(hipMemsetAsync(d_counters_, 0, 16 * sizeof(uint32_t), stream_));
-    }
+    if (int rc = join()) return rc;
+    for (auto& c : ctx_)
+        if (c.d_counters)   // the status bits are sticky across frames: a new configuration starts clean
+            TOPO_HIP_TRY(hipMemsetAsync(c.d_counters, 0, 16 * sizeof(uint32_t), pipeline_depth_ > 1 && c.stream ? c.stream : stream_));
     return TOPO_OK;
 }
 
 int TerrainRenderer::get_timings(float out[TOPO_TIMING_SLOTS]) {
     for (int i = 0; i < TOPO_TIMING_SLOTS; ++i) out[i] = 0.0f;
     if (int rc = bind_device()) return rc;
-    if (frame_timed_) {
+    // depth 1: the last frame.  Pipelined: the OLDEST frame in flight (the context the next submission will reuse), so
+    // that reading timings every frame does not wait for the frame just submitted
+    FrameCtx& c = ctx_[pipeline_depth_ > 1 ? next_ctx_ : last_ctx_];
+    hipEvent_t* ev_ = c.ev;
+    if (c.timed) {
         TOPO_HIP_TRY(hipEventSynchronize(ev_[8]));
         float d[8];
         for (int i = 0; i < 8; ++i) TOPO_HIP_TRY(hipEventElapsedTime(&d[i], ev_[i], ev_[i + 1]));
@@ -508,17 +575,19 @@ int TerrainRenderer::get_timings(float out[TOPO_TIMING_SLOTS]) {
         TOPO_HIP_TRY(hipEventElapsedTime(&out[6], ev_[0], ev_[8]));
     }
     if (load_timed_) {
-        TOPO_HIP_TRY(hipEventSynchronize(ev_[10]));
-        TOPO_HIP_TRY(hipEventElapsedTime(&out[7], ev_[9], ev_[10]));
+        TOPO_HIP_TRY(hipEventSynchronize(load_ev_[1]));
+        TOPO_HIP_TRY(hipEventElapsedTime(&out[7], load_ev_[0], load_ev_[1]));
     }
     return TOPO_OK;
 }
 
 int TerrainRenderer::get_counters(uint32_t out[6]) {
     for (int i = 0; i < 6; ++i) out[i] = 0;
+    FrameCtx& fc = ctx_[last_ctx_];
+    void* d_counters_ = fc.d_counters;
     if (!d_counters_) return TOPO_OK;
     if (int rc = bind_device()) return rc;
-    TOPO_HIP_TRY(hipStreamSynchronize(stream_));
+    TOPO_HIP_TRY(hipStreamSynchronize(pipeline_depth_ > 1 ? fc.stream : stream_));
     uint32_t c[16];
     TOPO_HIP_TRY(hipMemcpy(c, d_counters_, sizeof c, hipMemcpyDeviceToHost));
     if (getenv("TOPO_DEBUG_COUNTERS")) {   // raw queue counters, for kernel experiments

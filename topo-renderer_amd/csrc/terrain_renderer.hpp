@@ -49,6 +49,8 @@ class TerrainRenderer {
 
     int set_stream(hipStream_t s);
     int synchronize();
+    int set_pipeline_depth(int depth);
+    int join();
     int set_normals_lds_rows(int rows);
     int set_queue_caps(uint32_t big_cap, uint32_t rare_cap);
     int get_timings(float out[TOPO_TIMING_SLOTS]);
@@ -90,23 +92,39 @@ class TerrainRenderer {
     float occlusion_split_m_ = 90000.0f;   // flat optimum 60..120 km at c4 (profiles/README.md)
 
     hipStream_t own_stream_ = nullptr, stream_ = nullptr;
-    static constexpr int kNumEvents = 11;
-    hipEvent_t ev_[kNumEvents] = {};
-    bool frame_timed_ = false, load_timed_ = false;
+    static constexpr int kNumEvents = 9;
+    hipEvent_t load_ev_[2] = {};
+    bool load_timed_ = false;
+
+    // Everything one frame in flight owns.  With pipeline depth 1 (default) there is one context and it runs on
+    // stream_; with depth d > 1 topo_render_views_device rotates through d contexts, each on a stream of its own, so
+    // that the memory-latency-bound cull/raster phases of one frame run under the ALU-bound resolve of the previous one.
+    struct FrameCtx {
+        hipStream_t stream = nullptr;        // own stream (depth > 1)
+        hipEvent_t ev[kNumEvents] = {};
+        hipEvent_t done = nullptr;
+        bool timed = false, pending = false;
+        void* d_vis = nullptr;      size_t cap_vis = 0;
+        void* d_dirty = nullptr;    size_t cap_dirty = 0;   // one mark per 64 visibility keys (topo_kernels.hip: struct Vis)
+        void* d_work = nullptr;     size_t cap_work = 0;
+        void* d_work2 = nullptr;    size_t cap_work2 = 0;
+        void* d_far = nullptr;      size_t cap_far = 0;
+        void* d_big = nullptr;      size_t cap_big = 0;
+        void* d_rare = nullptr;     size_t cap_rare = 0;
+        void* d_counters = nullptr; size_t cap_counters = 0;
+    };
+    static constexpr int kMaxPipeline = 4;
+    FrameCtx ctx_[kMaxPipeline];
+    int pipeline_depth_ = 1, next_ctx_ = 0, last_ctx_ = 0;
+    int init_ctx(FrameCtx& c, bool own_stream);
+    int ensure_on(hipStream_t s, void** p, size_t* cap, size_t need);
+    int render_frame(FrameCtx& c, hipStream_t s, uint32_t n, const topo_uniforms* views, uint32_t w, uint32_t h, const OutputParams& out);
 
     // grow-only device buffers
     void* d_tiles_ = nullptr;    size_t cap_tiles_ = 0;
     void* d_views_ = nullptr;    size_t cap_views_ = 0;
-    void* d_vis_ = nullptr;      size_t cap_vis_ = 0;
-    void* d_dirty_ = nullptr;    size_t cap_dirty_ = 0;   // one mark per 64 visibility keys (topo_kernels.hip: struct Vis)
-    void* d_work_ = nullptr;     size_t cap_work_ = 0;
-    void* d_work2_ = nullptr;    size_t cap_work2_ = 0;
-    void* d_far_ = nullptr;      size_t cap_far_ = 0;
-    void* d_big_ = nullptr;      size_t cap_big_ = 0;
-    void* d_rare_ = nullptr;     size_t cap_rare_ = 0;
     void* d_edge_jobs_ = nullptr;   size_t cap_edge_jobs_ = 0;
     void* d_corner_jobs_ = nullptr; size_t cap_corner_jobs_ = 0;
-    void* d_counters_ = nullptr; size_t cap_counters_ = 0;
     void* d_out_rgba_ = nullptr; size_t cap_out_rgba_ = 0;
     void* d_out_depth_ = nullptr; size_t cap_out_depth_ = 0;
     static constexpr int kViewSlots = 16;

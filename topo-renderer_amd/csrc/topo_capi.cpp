@@ -159,6 +159,16 @@ int topo_probe_sincos(topo_ctx* ctx, const float* x, float* s, float* c, size_t 
     TOPO_CALL(ctx->r->probe_sincos(x, s, c, n));
 }
 
+int topo_set_pipeline_depth(topo_ctx* ctx, int32_t depth) {
+    TOPO_GUARD(ctx);
+    TOPO_CALL(ctx->r->set_pipeline_depth(depth));
+}
+
+int topo_join(topo_ctx* ctx) {
+    TOPO_GUARD(ctx);
+    TOPO_CALL(ctx->r->join());
+}
+
 int topo_probe_div(topo_ctx* ctx, int32_t kind, const float* x, const float* y, float* out, size_t n) {
     TOPO_GUARD(ctx);
     TOPO_CALL(ctx->r->probe_div(kind, x, y, out, n));
