@@ -302,8 +302,12 @@ class TerrainRenderer:
 
     def render_views_device(self, uniforms_list, width, height, rgba_ptr: int, rgba_view_stride: int, rgba_pitch: int,
                             depth_ptr: int = 0, depth_view_stride: int = 0, depth_pitch: int = 0):
-        us = np.ascontiguousarray(np.stack([np.ascontiguousarray(u).view(np.uint8).reshape(160) for u in uniforms_list]))
-        self._check(lib().topo_render_views_device(self._h, len(uniforms_list), _p(us), width, height,
+        if isinstance(uniforms_list, np.ndarray) and uniforms_list.dtype == np.uint8 and uniforms_list.ndim == 2:
+            us = np.ascontiguousarray(uniforms_list)           # already packed: (n_views, 160) bytes
+            assert us.shape[1] == 160
+        else:
+            us = np.ascontiguousarray(np.stack([np.ascontiguousarray(u).view(np.uint8).reshape(160) for u in uniforms_list]))
+        self._check(lib().topo_render_views_device(self._h, len(us), _p(us), width, height,
                                                    C.c_void_p(rgba_ptr), rgba_view_stride, rgba_pitch,
                                                    C.c_void_p(depth_ptr) if depth_ptr else None, depth_view_stride, depth_pitch))
 
