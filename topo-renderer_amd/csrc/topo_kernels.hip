@@ -1054,7 +1054,7 @@ __global__ __launch_bounds__(256, TOPO_RESOLVE_WGS) void k_resolve(FrameParams P
                 if (i == 0 && j == 0) continue;
                 ln[k++] = s_lin[ty + 1 + j][tx + 1 + i];
             }
-        const uint32_t out = post_pixel(s_thresh, s_decode, c8, s_lin[ty + 1][tx + 1], ln, lut);
+        const uint32_t out = post_pixel_t<true>(s_thresh, s_decode, c8, s_lin[ty + 1][tx + 1], ln, lut);
         *reinterpret_cast<uint32_t*>(rgba_col + (size_t)py * O.rgba_pitch) = out;
         if (depth_col) *reinterpret_cast<uint32_t*>(depth_col + (size_t)py * O.depth_pitch) = s_raw[ty][tx];
     }

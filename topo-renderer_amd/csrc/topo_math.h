@@ -309,9 +309,9 @@ TOPO_HD void shade_fragment(int view_mode, f3 sun, float cam_x, float cam_y, flo
 // ---- post pass (postprocessing_shader.wgsl:68-96) -------------------------------------------------
 // `c8` = the render-target texel (sRGB8 rgb + unorm8 alpha); taps in the shader's loop order (i outer = x
 // offset -1..1, j inner = y offset -1..1, centre skipped).
-// `lut` (may be null) selects srgb_encode_lut over srgb_encode: same result, fewer probes.
-TOPO_HD uint32_t post_pixel(const float* thresh, const float* decode, uint32_t c8, float center, const float ln[8],
-                            const uint8_t* lut = nullptr) {
+// kLut selects srgb_encode_lut (with `lut`) over srgb_encode: same result, fewer probes.
+template <bool kLut>
+TOPO_HD uint32_t post_pixel_t(const float* thresh, const float* decode, uint32_t c8, float center, const float ln[8], const uint8_t* lut) {
     // center / ln[] are ALREADY linear_depth() of the depth taps (each is a pure function of its texel, so a
     // kernel may compute it once per texel and share it between the up to nine pixels that tap it).
     float contour = 8.0f * center;
@@ -327,11 +327,14 @@ TOPO_HD uint32_t post_pixel(const float* thresh, const float* decode, uint32_t c
     const float g = decode[(c8 >> 8) & 255u] * (1.0f - a) + 0.0f * a;
     const float b = decode[(c8 >> 16) & 255u] * (1.0f - a) + 0.0f * a;
     const float al = from_unorm8(c8 >> 24) * (1.0f - a) + 1.0f * a;
-    if (lut)
+    if (kLut)
         return srgb_encode_lut(thresh, lut, r) | (srgb_encode_lut(thresh, lut, g) << 8) | (srgb_encode_lut(thresh, lut, b) << 16) |
                (to_unorm8(al) << 24);
     return srgb_encode(thresh, r) | (srgb_encode(thresh, g) << 8) | (srgb_encode(thresh, b) << 16) |
            (to_unorm8(al) << 24);
+}
+TOPO_HD uint32_t post_pixel(const float* thresh, const float* decode, uint32_t c8, float center, const float ln[8]) {
+    return post_pixel_t<false>(thresh, decode, c8, center, ln, nullptr);
 }
 
 }  // namespace topo
