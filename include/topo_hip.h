@@ -198,6 +198,23 @@ void topo_to_raster(const float raster_point[2], const float model_point[2], con
 int topo_height_value_at(const float* heights, uint32_t w, uint32_t h, const float raster_point[2], const float model_point[2],
                          const float pixel_scale[2], double longitude, double latitude, float* out);
 
+/* ---- GeoTIFF decode: fetch_terrain's decode step, background_runner.rs:113-136 ------------------
+ * The reference hands the downloaded bytes to the `tiff` crate (0.11.2): find_tag(ModelPixelScale / ModelTiepoint /
+ * ModelTransformation) -> CoordinateTransform::from_geo_tag_data, read_image_to_buffer -> DecodingResult::F32, dimensions().
+ * Supported here: classic TIFF of either byte order, first IFD, strips or tiles, one 32-bit IEEE float sample per pixel,
+ * compression none / Deflate / LZW / PackBits, predictor none / horizontal / floating point.  The container is parsed
+ * and the byte streams are decompressed on the host; predictor, byte order and tile placement run on the GPU.
+ * Errors: TOPO_ERR_INVALID (malformed file, IncorrectGeoTagData), TOPO_ERR_UNSUPPORTED (BigTIFF, other sample layouts or
+ * compressions, IncorrectGeoTags).  Unlike the reference, which ignores a failed read_image_to_buffer and carries on with
+ * an empty raster, a decode error is reported. */
+/* Size and CoordinateTransform of the first image; no GPU involved. */
+int topo_geotiff_info(const uint8_t* bytes, size_t n_bytes, uint32_t* width, uint32_t* height, float raster_point[2],
+                      float model_point[2], float pixel_scale[2]);
+/* The raster as width*height host floats (row-major, row 0 first) -- what the reference keeps for get_height_value_at. */
+int topo_geotiff_decode(topo_ctx* ctx, const uint8_t* bytes, size_t n_bytes, float* heights_out, size_t capacity_floats);
+/* Decode + add_terrain in one step; the raster goes from the decoder to the tile without leaving the device. */
+int topo_add_terrain_geotiff(topo_ctx* ctx, int32_t lat_deg, int32_t lon_deg, const uint8_t* bytes, size_t n_bytes);
+
 /* UiController::get_locations_range(location, range_dist)                    control/ui_controller.rs:61-83
  * (the tile working set around a viewpoint; the reference calls it with 100 000 m).  Writes up
  * to `cap` (lat_deg, lon_deg) pairs in the reference's order -- sorted by (|lat - c_lat|, |lon - c_lon|), stable over

@@ -506,3 +506,83 @@ def test_pipelined_frames_equal_serial_frames(topo, orc):
     assert_same_frame(g.render(), o.render(), "topo_render with a pipeline depth of 2")
     with pytest.raises(topo.TopoError):
         g.set_pipeline_depth(9)
+
+
+GEOTIFF_CASES = [
+    dict(),                                                     # COP90 style: Deflate + floating-point predictor, one strip
+    dict(byteorder=">"),
+    dict(tile=(16, 16)),                                        # tiles, padded at the right / bottom edge
+    dict(tile=(64, 32), byteorder=">", predictor=3),
+    dict(rows_per_strip=7, predictor=3, compression="adobe_deflate_old"),
+    dict(rows_per_strip=1, predictor=2),
+    dict(predictor=2, byteorder=">", tile=(32, 16)),
+    dict(compression="none", predictor=1),
+    dict(compression="none", predictor=1, byteorder=">", rows_per_strip=3),
+    dict(compression="packbits", predictor=1, rows_per_strip=5),
+    dict(compression="packbits", predictor=3),
+]
+
+
+@pytest.mark.parametrize("kw", GEOTIFF_CASES, ids=[f"t{i}" for i in range(len(GEOTIFF_CASES))])
+def test_geotiff_decode_bit_exact(topo, kw):
+    """topo_geotiff_decode returns the float bits the encoder was given (tests/tiff_writer.py, independent of the decoder):
+    specials and denormals included."""
+    from tiff_writer import write_geotiff
+    rng = np.random.default_rng(11)
+    a = rng.normal(1200.0, 900.0, (45, 77)).astype(np.float32)
+    a[0, :6] = [0.0, -0.0, np.inf, -np.inf, 1e-42, -32768.0]
+    a[3, 5] = np.nan
+    r = topo.TerrainRenderer(8, 8)
+    got = r.decode_geotiff(write_geotiff(a, **kw))
+    assert got.shape == a.shape and np.array_equal(got.view(np.uint32), a.view(np.uint32))
+
+
+def test_geotiff_decode_of_libtiff_files(topo):
+    """Files written by Pillow/libtiff (an encoder this repository does not control), incl. LZW and the predictors it offers."""
+    pytest.importorskip("PIL")
+    import io
+    from PIL import Image, TiffImagePlugin
+    rng = np.random.default_rng(12)
+    a = rng.normal(800.0, 500.0, (120, 131)).astype(np.float32)
+    r = topo.TerrainRenderer(8, 8)
+    n_ok = 0
+    for comp in (None, "tiff_adobe_deflate", "tiff_lzw", "packbits"):
+        for pred in (1, 3):
+            ifd = TiffImagePlugin.ImageFileDirectory_v2()
+            ifd[33550] = (1 / 1200, 1 / 1200, 0.0)
+            ifd.tagtype[33550] = 12
+            ifd[33922] = (0.0, 0.0, 0.0, 11.0, 47.0, 0.0)
+            ifd.tagtype[33922] = 12
+            if pred != 1:
+                if comp in (None, "packbits"):
+                    continue                              # libtiff applies predictors only with LZW / Deflate
+                ifd[317] = pred
+            buf = io.BytesIO()
+            Image.fromarray(a, mode="F").save(buf, format="TIFF", compression=comp, tiffinfo=ifd)
+            back = np.array(Image.open(io.BytesIO(buf.getvalue())))          # libtiff's own decode: the file is sound
+            assert np.array_equal(back.view(np.uint32), a.view(np.uint32))
+            got = r.decode_geotiff(buf.getvalue())
+            assert np.array_equal(got.view(np.uint32), a.view(np.uint32)), (comp, pred)
+            n_ok += 1
+    assert n_ok >= 6
+
+
+def test_add_terrain_geotiff_equals_add_terrain(topo, orc):
+    """Decode + add_terrain in one call renders the frame add_terrain of the same raster renders (and the oracle's)."""
+    from tiff_writer import write_geotiff
+    sc = Scene(64, 1, 2, eye_dh=80)
+    g, o = both(topo, orc, 160, 96)
+    for loc in sc.locs:
+        rp, mp, ps = sc.transform(loc)
+        data = write_geotiff(sc.heights[loc], tile=(32, 32), pixel_scale=(float(ps[0]), float(ps[1]), 0.0),
+                             tie_points=(float(rp[0]), float(rp[1]), 0.0, float(mp[0]), float(mp[1]), 0.0))
+        w, h, ct = topo.geotiff_info(data)
+        assert (w, h) == (64, 64)
+        assert np.array_equal(ct.model_point, np.asarray(mp, np.float32)) and np.array_equal(ct.pixel_scale, np.asarray(ps, np.float32))
+        g.add_terrain_geotiff(loc[0], loc[1], data)
+    sc.load(o)
+    u, pu = sc.uniforms(160, 96, 40, 12, 70, 0), topo.post_uniforms(160, 96)
+    g.update(160, 96, u, pu)
+    o.update(160, 96, u, pu)
+    assert_same_frame(g.render(), o.render(), "tiles loaded from GeoTIFF bytes")
+    assert np.array_equal(g.read_normals(*sc.locs[0]), o.read_normals(sc.locs[0][0], sc.locs[0][1], 64, 64))

@@ -108,6 +108,9 @@ def lib():
             "topo_synth_tile": (None, [i32, i32, u32, u32, u32, vp]),
             "topo_locations_range": (u32, [f32, f32, f32, vp, u32]),
             "topo_coordinate_transform": (C.c_int, [vp, u32, vp, u32, vp, vp, vp, vp]),
+            "topo_geotiff_info": (C.c_int, [vp, sz, vp, vp, vp, vp, vp]),
+            "topo_geotiff_decode": (C.c_int, [vp, vp, sz, vp, sz]),
+            "topo_add_terrain_geotiff": (C.c_int, [vp, i32, i32, vp, sz]),
             "topo_to_model": (None, [vp, vp, vp, f32, f32, vp]),
             "topo_to_raster": (None, [vp, vp, vp, f32, f32, vp]),
             "topo_height_value_at": (C.c_int, [vp, u32, u32, vp, vp, vp, C.c_double, C.c_double, vp]),
@@ -211,6 +214,17 @@ class CoordinateTransform:
         return None if rc != 0 else float(out[0])
 
 
+def geotiff_info(data: bytes):
+    """(width, height, CoordinateTransform) of a GeoTIFF's first image (topo_geotiff_info); no GPU involved."""
+    buf = np.frombuffer(data, np.uint8)
+    w, h = C.c_uint32(), C.c_uint32()
+    rp, mp, sc = (np.zeros(2, np.float32) for _ in range(3))
+    rc = lib().topo_geotiff_info(_p(buf), buf.size, C.byref(w), C.byref(h), _p(rp), _p(mp), _p(sc))
+    if rc != 0:
+        raise TopoError(rc, "GeoTIFF container or geo tags not usable")
+    return int(w.value), int(h.value), CoordinateTransform(rp, mp, sc)
+
+
 def post_uniforms(width, height, pixelize_n=100.0) -> np.ndarray:
     """PostprocessingUniforms::new (render/data.rs:82-89)."""
     return np.array([width, height, pixelize_n, 0.0], dtype=np.float32)
@@ -296,6 +310,20 @@ class TerrainRenderer:
         depth = np.zeros((h, pitch // 4), np.float32)
         self._check(lib().topo_render(self._h, _p(rgba), w * 4, _p(depth), pitch))
         return rgba, (depth if padded_depth else depth[:, :w])
+
+    def decode_geotiff(self, data: bytes) -> np.ndarray:
+        """The f32 raster of a GeoTIFF's first image (topo_geotiff_decode: host container work, GPU predictor/layout)."""
+        w, h, _ = geotiff_info(data)
+        buf = np.frombuffer(data, np.uint8)
+        out = np.empty((h, w), np.float32)
+        self._check(lib().topo_geotiff_decode(self._h, _p(buf), buf.size, _p(out), out.size))
+        return out
+
+    def add_terrain_geotiff(self, lat_deg: int, lon_deg: int, data: bytes):
+        buf = np.frombuffer(data, np.uint8)
+        self._check(lib().topo_add_terrain_geotiff(self._h, lat_deg, lon_deg, _p(buf), buf.size))
+        w, h, _ = geotiff_info(data)
+        self.tile_size = (w, h)
 
     def recompute_normals(self):
         self._check(lib().topo_recompute_normals(self._h))

@@ -1,6 +1,8 @@
 // terrain_renderer.cpp -- host orchestration of the HIP terrain path (see terrain_renderer.hpp).
 #include "terrain_renderer.hpp"
 
+#include "geotiff.hpp"
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -606,6 +608,94 @@ int TerrainRenderer::read_normals(int32_t lat, int32_t lon, uint8_t* out) {
     TOPO_HIP_TRY(hipStreamSynchronize(stream_));
     TOPO_HIP_TRY(hipMemcpy(out, t->d_normals, (size_t)tile_w_ * tile_h_ * 4, hipMemcpyDeviceToHost));
     return TOPO_OK;
+}
+
+// ---- GeoTIFF (fetch_terrain's decode step, background_runner.rs:113-136) ---------------------------------------
+int geotiff_transform(const TiffInfo& ti, float rp[2], float mp[2], float ps[2]) {
+    // CoordinateTransform::from_geo_tag_data (coordinate_transform.rs:23-57)
+    if (ti.has_model_transformation) return TOPO_ERR_UNSUPPORTED;
+    if (!ti.has_pixel_scale || !ti.has_tie_points) return TOPO_ERR_UNSUPPORTED;
+    if (ti.pixel_scale.size() != 3 || ti.tie_points.size() != 6) return TOPO_ERR_INVALID;
+    rp[0] = (float)ti.tie_points[0]; rp[1] = (float)ti.tie_points[1];
+    mp[0] = (float)ti.tie_points[3]; mp[1] = (float)ti.tie_points[4];
+    ps[0] = (float)ti.pixel_scale[0]; ps[1] = (float)ti.pixel_scale[1];
+    return TOPO_OK;
+}
+
+// Decodes the first image of the file into a fresh device raster (caller frees *d_heights with hipFree).
+int TerrainRenderer::geotiff_to_device(const uint8_t* bytes, size_t n, float** d_heights, uint32_t* w, uint32_t* h, float rp[2],
+                                       float mp[2], float ps[2]) {
+    *d_heights = nullptr;
+    TiffInfo ti;
+    std::string e;
+    if (int rc = tiff_parse(bytes, n, ti, e)) return fail(rc, "GeoTIFF: " + e);
+    if (int rc = geotiff_transform(ti, rp, mp, ps))
+        return fail(rc, rc == TOPO_ERR_UNSUPPORTED ? "GeoTIFF: IncorrectGeoTags (ModelPixelScale + ModelTiepoint without ModelTransformation required)"
+                                                    : "GeoTIFF: IncorrectGeoTagData (ModelPixelScale needs 3 and ModelTiepoint 6 values)");
+    if (int rc = bind_device()) return rc;
+    // host: the byte streams of all strips/tiles, decompressed back to back (4-byte aligned: sizes are multiples of 4)
+    std::vector<TiffSegDev> segs;
+    std::vector<uint32_t> row_seg;
+    size_t total = 0;
+    for (const TiffSegment& s : ti.segments) {
+        TiffSegDev d{};
+        d.byte_off = total; d.row0 = (uint32_t)row_seg.size();
+        d.x0 = s.x0; d.y0 = s.y0; d.w = s.w; d.h = s.h;
+        for (uint32_t r = 0; r < s.h; ++r) row_seg.push_back((uint32_t)segs.size());
+        segs.push_back(d);
+        total += (size_t)s.w * s.h * 4;
+    }
+    std::vector<uint8_t> staged(total);
+    for (size_t k = 0; k < segs.size(); ++k)
+        if (int rc = tiff_segment_bytes(bytes, n, ti, ti.segments[k], staged.data() + segs[k].byte_off, e)) return fail(rc, "GeoTIFF: " + e);
+    uint8_t* d_bytes = nullptr;
+    TiffSegDev* d_segs = nullptr;
+    uint32_t* d_rows = nullptr;
+    float* d_out = nullptr;
+    hipError_t he = hipMalloc((void**)&d_bytes, total ? total : 4);
+    if (he == hipSuccess) he = hipMalloc((void**)&d_segs, segs.size() * sizeof(TiffSegDev));
+    if (he == hipSuccess) he = hipMalloc((void**)&d_rows, row_seg.size() * sizeof(uint32_t));
+    if (he == hipSuccess) he = hipMalloc((void**)&d_out, (size_t)ti.width * ti.height * sizeof(float));
+    if (he == hipSuccess) he = hipMemcpyAsync(d_bytes, staged.data(), total, hipMemcpyHostToDevice, stream_);
+    if (he == hipSuccess) he = hipMemcpyAsync(d_segs, segs.data(), segs.size() * sizeof(TiffSegDev), hipMemcpyHostToDevice, stream_);
+    if (he == hipSuccess) he = hipMemcpyAsync(d_rows, row_seg.data(), row_seg.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream_);
+    if (he == hipSuccess) {
+        launch_tiff_rows(d_bytes, d_segs, d_rows, (uint32_t)row_seg.size(), d_out, ti.width, ti.height, ti.predictor, ti.big_endian, stream_);
+        he = hipStreamSynchronize(stream_);          // the staging vectors are only borrowed for the call
+    }
+    (void)hipFree(d_bytes); (void)hipFree(d_segs); (void)hipFree(d_rows);
+    if (he != hipSuccess) {
+        (void)hipFree(d_out);
+        return hip_fail(he, "GeoTIFF decode");
+    }
+    *d_heights = d_out;
+    *w = ti.width;
+    *h = ti.height;
+    return TOPO_OK;
+}
+
+int TerrainRenderer::geotiff_decode(const uint8_t* bytes, size_t n, float* heights_out, size_t capacity) {
+    if (!bytes || !heights_out) return fail(TOPO_ERR_INVALID, "null argument");
+    float* d = nullptr;
+    uint32_t w = 0, h = 0;
+    float rp[2], mp[2], ps[2];
+    if (int rc = geotiff_to_device(bytes, n, &d, &w, &h, rp, mp, ps)) return rc;
+    int rc = TOPO_OK;
+    if ((size_t)w * h > capacity) rc = fail(TOPO_ERR_CAPACITY, "heights_out is smaller than the image");
+    else if (hipMemcpy(heights_out, d, (size_t)w * h * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(TOPO_ERR_HIP, "copy of the decoded raster failed");
+    (void)hipFree(d);
+    return rc;
+}
+
+int TerrainRenderer::add_terrain_geotiff(int32_t lat, int32_t lon, const uint8_t* bytes, size_t n) {
+    if (!bytes) return fail(TOPO_ERR_INVALID, "null argument");
+    float* d = nullptr;
+    uint32_t w = 0, h = 0;
+    float rp[2], mp[2], ps[2];
+    if (int rc = geotiff_to_device(bytes, n, &d, &w, &h, rp, mp, ps)) return rc;
+    const int rc = add_terrain(lat, lon, d, true, w, h, rp, mp, ps);      // copies device-to-device
+    (void)hipFree(d);
+    return rc;
 }
 
 int TerrainRenderer::probe_sincos(const float* x, float* s, float* c, size_t n) {

@@ -57,6 +57,9 @@ class TerrainRenderer {
     int get_counters(uint32_t out[6]);
     int set_occlusion_split(float metres);
     int read_normals(int32_t lat, int32_t lon, uint8_t* out);
+    int geotiff_to_device(const uint8_t* bytes, size_t n, float** d_heights, uint32_t* w, uint32_t* h, float rp[2], float mp[2], float ps[2]);
+    int geotiff_decode(const uint8_t* bytes, size_t n, float* heights_out, size_t capacity);
+    int add_terrain_geotiff(int32_t lat, int32_t lon, const uint8_t* bytes, size_t n);
     int probe_sincos(const float* x, float* s, float* c, size_t n);
     int probe_div(int32_t kind, const float* x, const float* y, float* out, size_t n);
     int visible_peaks(uint32_t n, const float* peaks, uint8_t* visible, uint32_t* xy);

@@ -4,6 +4,7 @@
 #include <new>
 #include <string>
 
+#include "geotiff.hpp"
 #include "terrain_renderer.hpp"
 
 struct topo_ctx {
@@ -238,6 +239,26 @@ int topo_height_value_at(const float* heights, uint32_t w, uint32_t h, const flo
     if (index >= (unsigned __int128)w * h) return TOPO_ERR_NOT_FOUND;
     *out = heights[(size_t)index];
     return TOPO_OK;
+}
+
+int topo_geotiff_info(const uint8_t* bytes, size_t n, uint32_t* w, uint32_t* h, float rp[2], float mp[2], float ps[2]) {
+    if (!bytes || !w || !h || !rp || !mp || !ps) return TOPO_ERR_INVALID;
+    topo::TiffInfo ti;
+    std::string e;
+    if (int rc = topo::tiff_parse(bytes, n, ti, e)) return rc;
+    *w = ti.width;
+    *h = ti.height;
+    return topo::geotiff_transform(ti, rp, mp, ps);
+}
+
+int topo_geotiff_decode(topo_ctx* ctx, const uint8_t* bytes, size_t n, float* heights_out, size_t capacity) {
+    TOPO_GUARD(ctx);
+    TOPO_CALL(ctx->r->geotiff_decode(bytes, n, heights_out, capacity));
+}
+
+int topo_add_terrain_geotiff(topo_ctx* ctx, int32_t lat, int32_t lon, const uint8_t* bytes, size_t n) {
+    TOPO_GUARD(ctx);
+    TOPO_CALL(ctx->r->add_terrain_geotiff(lat, lon, bytes, n));
 }
 
 uint32_t topo_locations_range(float latitude, float longitude, float range_dist, int32_t* out, uint32_t cap) {

@@ -107,6 +107,15 @@ void launch_visible_peaks(const float* proj16_dev, uint32_t w, uint32_t h, const
                           const float* peaks_xyz, uint8_t* visible, uint32_t* xy, hipStream_t s);
 
 // unit-test probes
+// GeoTIFF decode, device half: one workgroup per stored row of a strip/tile (geotiff.hpp).
+struct TiffSegDev {
+    uint64_t byte_off;       // of the segment's decompressed bytes in the staging buffer
+    uint32_t row0;           // index of its first row in the global row list
+    uint32_t x0, y0, w, h;   // position in the image, stored size
+    uint32_t pad_;
+};
+void launch_tiff_rows(uint8_t* bytes, const TiffSegDev* segs, const uint32_t* row_seg, uint32_t n_rows, float* out, uint32_t W, uint32_t H,
+                      uint32_t predictor, bool big_endian, hipStream_t s);
 void launch_probe_sincos(const float* x, float* s, float* c, size_t n, hipStream_t st);
 void launch_probe_div(int kind, const float* x, const float* y, float* out, size_t n, hipStream_t st);
 

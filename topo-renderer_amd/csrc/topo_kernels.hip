@@ -1080,6 +1080,71 @@ __global__ __launch_bounds__(256) void k_visible_peaks(const float* __restrict__
     xy[2 * i + 1] = vis ? y_pos : 0u;
 }
 
+// ---- GeoTIFF rows: predictor, byte order, placement --------------------------------------------------------
+// Inclusive prefix sum over `n` elements of a row held in global memory, in place, by one 256-thread workgroup: each
+// thread sums a contiguous chunk, the 256 partial sums are scanned in LDS, each thread rewrites its chunk.
+template <typename T, typename Load, typename Store>
+__device__ void row_prefix_sum(uint32_t n, Load load, Store store) {
+    __shared__ uint32_t part[256];
+    const uint32_t per = (n + 255) / 256, lo = min(threadIdx.x * per, n), hi = min(lo + per, n);
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; ++i) sum += load(i);
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (uint32_t off = 1; off < 256; off <<= 1) {
+        const uint32_t a = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+        __syncthreads();
+        part[threadIdx.x] += a;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - sum;      // exclusive prefix of this chunk
+    for (uint32_t i = lo; i < hi; ++i) {
+        run += load(i);
+        store(i, (T)run);
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_tiff_rows(uint8_t* __restrict__ bytes, const TiffSegDev* __restrict__ segs,
+                                                   const uint32_t* __restrict__ row_seg, float* __restrict__ out, uint32_t W, uint32_t H,
+                                                   uint32_t predictor, int big_endian) {
+    const TiffSegDev sg = segs[row_seg[blockIdx.x]];
+    const uint32_t r = blockIdx.x - sg.row0, y = sg.y0 + r;
+    uint8_t* row = bytes + sg.byte_off + (size_t)r * sg.w * 4;
+    auto word = [&](uint32_t i) {           // sample i of the row in the file's byte order -> native
+        const uint8_t* p = row + 4 * (size_t)i;
+        return big_endian ? ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]
+                          : ((uint32_t)p[3] << 24) | ((uint32_t)p[2] << 16) | ((uint32_t)p[1] << 8) | p[0];
+    };
+    if (predictor == 3) {
+        // floating-point predictor: the row is stored as four byte planes, most significant first, the whole 4w-byte
+        // sequence differenced byte-wise (Adobe Photoshop TIFF Technical Note 3)
+        row_prefix_sum<uint8_t>(sg.w * 4, [&](uint32_t i) { return (uint32_t)row[i]; }, [&](uint32_t i, uint8_t v) { row[i] = v; });
+        for (uint32_t i = threadIdx.x; i < sg.w; i += 256) {
+            const uint32_t x = sg.x0 + i;
+            if (x < W && y < H)
+                out[(size_t)y * W + x] = __uint_as_float(((uint32_t)row[i] << 24) | ((uint32_t)row[sg.w + i] << 16) |
+                                                         ((uint32_t)row[2 * sg.w + i] << 8) | row[3 * sg.w + i]);
+        }
+        return;
+    }
+    if (predictor == 2) {                   // horizontal differencing of the 32-bit words
+        uint32_t* wrow = reinterpret_cast<uint32_t*>(row);      // segments start 4-byte aligned in the staging buffer
+        for (uint32_t i = threadIdx.x; i < sg.w; i += 256) wrow[i] = word(i);
+        __syncthreads();
+        row_prefix_sum<uint32_t>(sg.w, [&](uint32_t i) { return wrow[i]; }, [&](uint32_t i, uint32_t v) { wrow[i] = v; });
+        for (uint32_t i = threadIdx.x; i < sg.w; i += 256) {
+            const uint32_t x = sg.x0 + i;
+            if (x < W && y < H) out[(size_t)y * W + x] = __uint_as_float(wrow[i]);
+        }
+        return;
+    }
+    for (uint32_t i = threadIdx.x; i < sg.w; i += 256) {
+        const uint32_t x = sg.x0 + i;
+        if (x < W && y < H) out[(size_t)y * W + x] = __uint_as_float(word(i));
+    }
+}
+
 __global__ void k_probe_sincos(const float* x, float* s, float* c, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) sincos_f(x[i], s[i], c[i]);
@@ -1188,6 +1253,11 @@ void launch_visible_peaks(const float* proj16_dev, uint32_t w, uint32_t h, const
     if (n == 0) return;
     hipLaunchKernelGGL(k_visible_peaks, dim3((n + 255) / 256), dim3(256), 0, s, proj16_dev, w, h, depth, depth_pitch, n, peaks_xyz,
                        visible, xy);
+}
+
+void launch_tiff_rows(uint8_t* bytes, const TiffSegDev* segs, const uint32_t* row_seg, uint32_t n_rows, float* out, uint32_t W, uint32_t H,
+                      uint32_t predictor, bool big_endian, hipStream_t s) {
+    if (n_rows) hipLaunchKernelGGL(k_tiff_rows, dim3(n_rows), dim3(256), 0, s, bytes, segs, row_seg, out, W, H, predictor, big_endian ? 1 : 0);
 }
 
 void launch_probe_sincos(const float* x, float* s, float* c, size_t n, hipStream_t st) {
