@@ -4,6 +4,8 @@
 #include "geotiff.hpp"
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -646,8 +648,23 @@ int TerrainRenderer::geotiff_to_device(const uint8_t* bytes, size_t n, float** d
         total += (size_t)s.w * s.h * 4;
     }
     std::vector<uint8_t> staged(total);
-    for (size_t k = 0; k < segs.size(); ++k)
-        if (int rc = tiff_segment_bytes(bytes, n, ti, ti.segments[k], staged.data() + segs[k].byte_off, e)) return fail(rc, "GeoTIFF: " + e);
+    {   // strips/tiles are independent byte streams: inflate them on a few host threads
+        const unsigned hw = std::thread::hardware_concurrency();
+        const size_t n_thr = std::min<size_t>(segs.size(), std::min<unsigned>(hw ? hw : 1, 8));
+        std::vector<int> rcs(n_thr, TOPO_OK);
+        std::vector<std::string> errs(n_thr);
+        std::atomic<size_t> next{0};
+        auto work = [&](size_t tid) {
+            for (size_t k = next++; k < segs.size(); k = next++)
+                if (int rc = tiff_segment_bytes(bytes, n, ti, ti.segments[k], staged.data() + segs[k].byte_off, errs[tid])) { rcs[tid] = rc; return; }
+        };
+        std::vector<std::thread> pool;
+        for (size_t t = 1; t < n_thr; ++t) pool.emplace_back(work, t);
+        work(0);
+        for (auto& th : pool) th.join();
+        for (size_t t = 0; t < n_thr; ++t)
+            if (rcs[t]) return fail(rcs[t], "GeoTIFF: " + errs[t]);
+    }
     uint8_t* d_bytes = nullptr;
     TiffSegDev* d_segs = nullptr;
     uint32_t* d_rows = nullptr;
