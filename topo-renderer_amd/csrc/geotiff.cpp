@@ -128,6 +128,7 @@ int tiff_parse(const uint8_t* data, size_t n, TiffInfo& info, std::string& err) 
     if (!tile_off.empty()) {
         if (tile_w == 0 || tile_h == 0 || tile_w > 32768 || tile_h > 32768) { err = "bad tile size"; return TOPO_ERR_INVALID; }
         const uint32_t tx = (info.width + tile_w - 1) / tile_w, ty = (info.height + tile_h - 1) / tile_h;
+        if ((uint64_t)tx * ty > (1u << 20)) { err = "more than 2^20 tiles"; return TOPO_ERR_UNSUPPORTED; }
         if (tile_off.size() != (size_t)tx * ty || tile_cnt.size() != tile_off.size()) { err = "tile offset/byte-count tables have the wrong length"; return TOPO_ERR_INVALID; }
         for (uint32_t j = 0; j < ty; ++j)
             for (uint32_t i = 0; i < tx; ++i) {
@@ -145,8 +146,13 @@ int tiff_parse(const uint8_t* data, size_t n, TiffInfo& info, std::string& err) 
             info.segments.push_back(TiffSegment{strip_off[k], strip_cnt[k], 0, y0, info.width, hh});
         }
     }
-    for (const TiffSegment& s : info.segments)
+    uint64_t staged = 0;
+    for (const TiffSegment& s : info.segments) {
         if (!r.ok(s.offset, s.bytes)) { err = "a strip/tile lies outside the file"; return TOPO_ERR_INVALID; }
+        staged += (uint64_t)s.w * s.h * 4;
+    }
+    // bounds on what a file can make the decoder allocate: a million segments, 8 GiB of decompressed samples
+    if (info.segments.size() > (1u << 20) || staged > (1ull << 33)) { err = "more strips/tiles or padded samples than the decoder accepts"; return TOPO_ERR_UNSUPPORTED; }
     return TOPO_OK;
 }
 
