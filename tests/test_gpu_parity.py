@@ -586,3 +586,28 @@ def test_add_terrain_geotiff_equals_add_terrain(topo, orc):
     o.update(160, 96, u, pu)
     assert_same_frame(g.render(), o.render(), "tiles loaded from GeoTIFF bytes")
     assert np.array_equal(g.read_normals(*sc.locs[0]), o.read_normals(sc.locs[0][0], sc.locs[0][1], 64, 64))
+
+
+def test_sixty_four_views_in_one_submission(topo, orc):
+    """The per-submission limit (8 viewpoints x 8 sectors, as bench.py's batch mode submits them): every view equals the
+    oracle's frame for its uniforms; 65 views are rejected."""
+    import torch
+    sc = Scene(48, 2, 2, eye_dh=70)
+    g, o = both(topo, orc, 64, 48)
+    sc.load(g)
+    sc.load(o)
+    W, H = 64, 48
+    views = []
+    for y in range(8):
+        views += sc.panorama(W, H, yaw0_deg=13.0 * y)
+    packed = np.ascontiguousarray(np.stack([np.ascontiguousarray(u).view(np.uint8).reshape(160) for u in views]))
+    s = torch.zeros((64, H, W, 4), dtype=torch.uint8, device="cuda")
+    d = torch.zeros((64, H, W), dtype=torch.float32, device="cuda")
+    g.render_views_device(packed, W, H, s.data_ptr(), H * W * 4, W * 4, d.data_ptr(), H * W * 4, W * 4)
+    g.synchronize()
+    sh, dh = s.cpu().numpy(), d.cpu().numpy()
+    for k in (0, 7, 8, 21, 38, 63):
+        o.update(W, H, views[k], topo.post_uniforms(W, H))
+        assert_same_frame((sh[k], dh[k]), o.render(), f"view {k} of 64")
+    with pytest.raises(topo.TopoError):
+        g.render_views_device(views + views[:1], W, H, s.data_ptr(), H * W * 4, W * 4, d.data_ptr(), H * W * 4, W * 4)
