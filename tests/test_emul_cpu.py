@@ -151,6 +151,27 @@ def test_header_pipeline_matches_oracle(topo, orc, cfg):
     assert_same_frame(e.render(), o.render(), f"emul {cfg}")
 
 
+def test_header_pipeline_random_frames(topo, orc):
+    """The product headers on the CPU against the oracle over a seeded sweep of poses (steep pitches put triangles across the
+    near plane: the homogeneous-varyings path), sizes and view modes."""
+    rng = np.random.default_rng(77)
+    for i in range(12):
+        tile = int(rng.choice([16, 24, 40]))
+        n_lat, n_lon = int(rng.integers(1, 3)), int(rng.integers(1, 3))
+        dh = float(rng.choice([3.0, 12.0, 50.0, 400.0, 5000.0]))
+        sc = Scene(tile, n_lat, n_lon, eye_dh=dh)
+        W, H = int(rng.integers(17, 120)), int(rng.integers(9, 90))
+        e, o = emul.EmulRenderer(W, H, topo.terrain_uniforms), orc.OracleRenderer(W, H)
+        sc.load(e)
+        sc.load(o)
+        yaw, pitch = float(rng.uniform(0, 360)), float(rng.choice([rng.uniform(-20, 20), rng.uniform(20, 89)]))
+        fov, mode = float(rng.uniform(12, 150)), int(rng.integers(0, 3))
+        u, pu = sc.uniforms(W, H, yaw, pitch, fov, mode), topo.post_uniforms(W, H)
+        e.update(W, H, u, pu)
+        o.update(W, H, u, pu)
+        assert_same_frame(e.render(), o.render(), f"emul random {i}: tile {tile} dh {dh} {W}x{H} yaw {yaw:.1f} pitch {pitch:.1f} fov {fov:.1f} mode {mode}")
+
+
 def test_full_size_tile_matches_oracle(topo, orc):
     # one real-size COP90 tile (1200x1200, 2.9 M triangles) into a 512x256 frame
     sc = Scene(1200, 1, 1)
