@@ -1,14 +1,15 @@
 // topo_kernels.hip -- gfx950 (CDNA4, wave64) kernels of the terrain path.
 //
-//   load phase   k_block_minmax, k_normals_interior<ROWS>, k_normals_edge, k_normals_corner
-//                (compute_normals*.wgsl; once per add_terrain)
-//   frame phase  k_clear -> k_cull -> k_raster -> k_raster_big -> k_resolve
+//   load phase   k_tiff_rows (GeoTIFF predictor / layout), k_block_minmax (+ per-tile sin/cos tables and cull bounds),
+//                k_normals_interior<ROWS>, k_normals_edge, k_normals_corner (compute_normals*.wgsl; once per add_terrain)
+//   frame phase  k_clear -> k_cull -> [near] k_raster -> k_raster_rare -> k_raster_big -> k_phase_mark -> k_occlusion ->
+//                [far survivors] k_raster -> k_raster_rare -> k_raster_big -> k_resolve
 //                (render_shader.wgsl vs_main + fixed-function raster/depth, fs_main, postprocessing_shader.wgsl)
 //
 // The frame is a visibility-buffer renderer: every surviving fragment does a 64-bit atomic min of
 // (depth bits << 32 | draw-order id) -- the minimum reproduces CompareFunction::Less *and* the API-order
 // tie-break of the reference's in-order draws -- and one resolve pass shades the winner of each pixel and
-// applies the contour post pass.  HBM-bound integer/float work; no MFMA (there is no contraction).
+// applies the contour post pass.  Integer/float work without a contraction: no MFMA.
 //
 // Compiled with -ffp-contract=off: results must match the arithmetic spec bit for bit.
 #include "topo_kernels.h"
