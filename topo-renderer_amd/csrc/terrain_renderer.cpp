@@ -443,7 +443,6 @@ int TerrainRenderer::render_frame(FrameCtx& c, hipStream_t stream, uint32_t n, c
     launch_raster_big(p, stream);
     TOPO_HIP_TRY(hipEventRecord(c.ev[4], stream));
     if (p.split_m > 0.0f) {
-        launch_phase_mark(p, stream);
         launch_occlusion(p, stream);
     }
     TOPO_HIP_TRY(hipEventRecord(c.ev[5], stream));

@@ -96,7 +96,6 @@ void launch_normals_corners(const TileDev* tiles, const CornerJob* jobs, uint32_
 void launch_clear(const FrameParams& p, hipStream_t s);   // re-initialises the marked segments and the queue counters
 void launch_cull(const FrameParams& p, hipStream_t s);
 void launch_raster(const FrameParams& p, int phase, hipStream_t s);   // phase 0: near list, 1: far survivors
-void launch_phase_mark(const FrameParams& p, hipStream_t s);
 void launch_occlusion(const FrameParams& p, hipStream_t s);
 void launch_raster_rare(const FrameParams& p, hipStream_t s);
 void launch_raster_big(const FrameParams& p, hipStream_t s);

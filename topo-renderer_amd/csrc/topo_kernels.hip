@@ -2,7 +2,7 @@
 //
 //   load phase   k_tiff_rows (GeoTIFF predictor / layout), k_block_minmax (+ per-tile sin/cos tables and cull bounds),
 //                k_normals_interior<ROWS>, k_normals_edge, k_normals_corner (compute_normals*.wgsl; once per add_terrain)
-//   frame phase  k_clear -> k_cull -> [near] k_raster -> k_raster_rare -> k_raster_big -> k_phase_mark -> k_occlusion ->
+//   frame phase  k_clear -> k_cull -> [near] k_raster -> k_raster_rare -> k_raster_big -> k_occlusion ->
 //                [far survivors] k_raster -> k_raster_rare -> k_raster_big -> k_resolve
 //                (render_shader.wgsl vs_main + fixed-function raster/depth, fs_main, postprocessing_shader.wgsl)
 //
@@ -383,6 +383,12 @@ __global__ __launch_bounds__(256) void k_cull(FrameParams P) {
 // the block's lower bound -- then none of its fragments could pass `Less`.  Pixels in the gaps between tiles, or
 // anywhere nothing nearer has been drawn, keep the block alive, so the filter is exact by construction.
 __global__ __launch_bounds__(256) void k_occlusion(FrameParams P) {
+    // between the two raster phases: the rare/big queues keep growing, the second phase starts where the first ended
+    // (nothing enqueues while this kernel runs, and the consumers of the marks are launched after it)
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        P.counters[6] = P.counters[1];
+        P.counters[7] = P.counters[3];
+    }
     uint32_t count = P.counters[4];
     if (count > P.work_cap) count = P.work_cap;
     const uint32_t lane = threadIdx.x & 63;
@@ -417,13 +423,6 @@ __global__ __launch_bounds__(256) void k_occlusion(FrameParams P) {
     }
 }
 
-// Between the two raster phases: the rare/big queues keep growing, the second phase starts where the first ended.
-__global__ void k_phase_mark(uint32_t* counters) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        counters[6] = counters[1];
-        counters[7] = counters[3];
-    }
-}
 
 // ---- raster ------------------------------------------------------------------------------------------
 
@@ -1226,7 +1225,6 @@ void launch_raster(const FrameParams& p, int phase, hipStream_t s) {
     hipLaunchKernelGGL(k_raster, dim3(grid), dim3(256), 0, s, p, phase);
 }
 
-void launch_phase_mark(const FrameParams& p, hipStream_t s) { hipLaunchKernelGGL(k_phase_mark, dim3(1), dim3(64), 0, s, p.counters); }
 
 void launch_occlusion(const FrameParams& p, hipStream_t s) {
     if (p.n_tiles == 0) return;
