@@ -146,6 +146,11 @@ int topo_set_occlusion_split(topo_ctx* ctx, float metres);
  * [5] resolve+post  [6] total; of the last topo_recompute_normals: [7] load phase.  Synchronises. */
 #define TOPO_TIMING_SLOTS 8
 int topo_get_timings(topo_ctx* ctx, float out_ms[TOPO_TIMING_SLOTS]);
+/* Which of the slots [0]..[5] to measure (bit i = slot i; default all).  Every timing event between two kernels leaves the
+ * GPU idle for ~6 us while the marker completes -- 4 % of a c4 frame, a third of a c1 frame with all nine events -- so a
+ * caller that only wants one kernel's duration (bench.py: the dominant one) or none selects just that; unselected slots
+ * read 0, the total [6] is always measured. */
+int topo_set_timing_slots(topo_ctx* ctx, uint32_t slot_mask);
 
 /* Counters of the last topo_render* call: [0] near blocks rastered, [1] big-triangle items, [2] status bits
  * (bit 0: big-triangle queue overflowed -- handled in-lane, slower, still exact; bit 1: rare-triangle queue

@@ -639,3 +639,25 @@ def test_random_frames(topo, orc):
         o.update(W, H, u, pu)
         assert_same_frame(g.render(), o.render(), f"random frame {i}: tile {tile} {n_lat}x{n_lon} dh {dh} {W}x{H} yaw {yaw:.1f} pitch {pitch:.1f} fov {fov:.1f} mode {mode}")
         assert (g.counters()["status"] & 1) == 0
+
+
+def test_timing_slots_select_events(topo, orc):
+    """topo_set_timing_slots: unselected per-kernel slots read 0, the total is always measured, frames are unchanged."""
+    sc = Scene(64, 1, 1, eye_dh=60)
+    g, o = both(topo, orc, 96, 64)
+    sc.load(g)
+    sc.load(o)
+    u, pu = sc.uniforms(96, 64, 10, 5, 60, 0), topo.post_uniforms(96, 64)
+    o.update(96, 64, u, pu)
+    want = o.render()
+    g.update(96, 64, u, pu)
+    for names in (None, ("resolve",), ("raster", "cull"), ()):
+        g.set_timing_slots(names)
+        assert_same_frame(g.render(), want, f"timing slots {names}")
+        tm = g.timings()
+        assert tm["total"] > 0.0
+        for k in ("clear", "cull", "raster", "occlusion", "raster_big", "resolve"):
+            if names is None or k in names:
+                assert tm[k] > 0.0, (names, k)
+            else:
+                assert tm[k] == 0.0, (names, k)

@@ -93,6 +93,7 @@ def lib():
             "topo_get_timings": (C.c_int, [vp, vp]),
             "topo_get_counters": (C.c_int, [vp, vp]),
             "topo_set_occlusion_split": (C.c_int, [vp, f32]),
+            "topo_set_timing_slots": (C.c_int, [vp, u32]),
             "topo_read_normals": (C.c_int, [vp, i32, i32, vp]),
             "topo_probe_sincos": (C.c_int, [vp, vp, vp, vp, sz]),
             "topo_probe_div": (C.c_int, [vp, i32, vp, vp, vp, sz]),
@@ -368,6 +369,11 @@ class TerrainRenderer:
         self._check(lib().topo_get_counters(self._h, _p(out)))
         return {"blocks_rastered": int(out[0]) + int(out[5]), "big_items": int(out[1]), "status": int(out[2]), "rare_items": int(out[3]),
                 "near_blocks": int(out[0]), "far_tested": int(out[4]), "far_survived": int(out[5])}   # near/survivors: in 4-row strips
+
+    def set_timing_slots(self, names=None):
+        """Measure only the named per-kernel durations (TIMING_NAMES[:6]); None = all, () = just the total."""
+        mask = 0x3F if names is None else sum(1 << TIMING_NAMES.index(n) for n in names)
+        self._check(lib().topo_set_timing_slots(self._h, mask))
 
     def set_occlusion_split(self, metres: float):
         self._check(lib().topo_set_occlusion_split(self._h, metres))

@@ -432,29 +432,42 @@ int TerrainRenderer::render_frame(FrameCtx& c, hipStream_t stream, uint32_t n, c
     // clear -> cull -> [near blocks: raster, rare, big] -> occlusion test of the far blocks -> [survivors: raster,
     // rare, big] -> resolve.  Event slots: 0 clear, 1 cull, 2 raster(near), 3 rare+big(near), 4 occlusion,
     // 5 raster(far), 6 rare+big(far), 7 resolve.
-    TOPO_HIP_TRY(hipEventRecord(c.ev[0], stream));
+    // A timing event between two kernels costs ~6 us of idle GPU (the next kernel waits for the marker), so only the
+    // events the selected timing slots need are recorded (topo_set_timing_slots); slot -> stages: 0:{0} 1:{1} 2:{2,5} 3:{4}
+    // 4:{3,6} 5:{7}, stage i = ev[i]..ev[i+1]; the total (ev[0], ev[8]) is always kept.
+    uint32_t ev_need = 0x101u;
+    {
+        static const uint32_t stages_of_slot[6] = {1u << 0, 1u << 1, (1u << 2) | (1u << 5), 1u << 4, (1u << 3) | (1u << 6), 1u << 7};
+        for (int sl = 0; sl < 6; ++sl)
+            if (timing_slots_ & (1u << sl))
+                for (int st = 0; st < 8; ++st)
+                    if (stages_of_slot[sl] & (1u << st)) ev_need |= (3u << st);
+    }
+    c.ev_recorded = ev_need;
+    c.slots = timing_slots_;
+    if (ev_need & (1u << 0)) TOPO_HIP_TRY(hipEventRecord(c.ev[0], stream));
     launch_clear(p, stream);
-    TOPO_HIP_TRY(hipEventRecord(c.ev[1], stream));
+    if (ev_need & (1u << 1)) TOPO_HIP_TRY(hipEventRecord(c.ev[1], stream));
     launch_cull(p, stream);
-    TOPO_HIP_TRY(hipEventRecord(c.ev[2], stream));
+    if (ev_need & (1u << 2)) TOPO_HIP_TRY(hipEventRecord(c.ev[2], stream));
     launch_raster(p, 0, stream);
-    TOPO_HIP_TRY(hipEventRecord(c.ev[3], stream));
+    if (ev_need & (1u << 3)) TOPO_HIP_TRY(hipEventRecord(c.ev[3], stream));
     launch_raster_rare(p, stream);
     launch_raster_big(p, stream);
-    TOPO_HIP_TRY(hipEventRecord(c.ev[4], stream));
+    if (ev_need & (1u << 4)) TOPO_HIP_TRY(hipEventRecord(c.ev[4], stream));
     if (p.split_m > 0.0f) {
         launch_occlusion(p, stream);
     }
-    TOPO_HIP_TRY(hipEventRecord(c.ev[5], stream));
+    if (ev_need & (1u << 5)) TOPO_HIP_TRY(hipEventRecord(c.ev[5], stream));
     if (p.split_m > 0.0f) launch_raster(p, 1, stream);
-    TOPO_HIP_TRY(hipEventRecord(c.ev[6], stream));
+    if (ev_need & (1u << 6)) TOPO_HIP_TRY(hipEventRecord(c.ev[6], stream));
     if (p.split_m > 0.0f) {
         launch_raster_rare(p, stream);
         launch_raster_big(p, stream);
     }
-    TOPO_HIP_TRY(hipEventRecord(c.ev[7], stream));
+    if (ev_need & (1u << 7)) TOPO_HIP_TRY(hipEventRecord(c.ev[7], stream));
     launch_resolve(p, out, stream);
-    TOPO_HIP_TRY(hipEventRecord(c.ev[8], stream));
+    if (ev_need & (1u << 8)) TOPO_HIP_TRY(hipEventRecord(c.ev[8], stream));
     c.timed = true;
     TOPO_HIP_TRY(hipGetLastError());
     return TOPO_OK;
@@ -542,6 +555,11 @@ int TerrainRenderer::set_normals_lds_rows(int rows) {
     return TOPO_OK;
 }
 
+int TerrainRenderer::set_timing_slots(uint32_t mask) {
+    timing_slots_ = mask & 0x3Fu;
+    return TOPO_OK;
+}
+
 int TerrainRenderer::set_occlusion_split(float metres) {
     if (!(metres >= 0.0f)) return fail(TOPO_ERR_INVALID, "split must be >= 0");
     occlusion_split_m_ = metres;
@@ -568,13 +586,18 @@ int TerrainRenderer::get_timings(float out[TOPO_TIMING_SLOTS]) {
     if (c.timed) {
         TOPO_HIP_TRY(hipEventSynchronize(ev_[8]));
         float d[8];
-        for (int i = 0; i < 8; ++i) TOPO_HIP_TRY(hipEventElapsedTime(&d[i], ev_[i], ev_[i + 1]));
+        for (int i = 0; i < 8; ++i) {
+            d[i] = 0.0f;
+            if ((c.ev_recorded >> i & 3u) == 3u) TOPO_HIP_TRY(hipEventElapsedTime(&d[i], ev_[i], ev_[i + 1]));
+        }
         out[0] = d[0];                // clear
         out[1] = d[1];                // cull
         out[2] = d[2] + d[5];         // raster: near blocks + far survivors
         out[3] = d[4];                // occlusion test
         out[4] = d[3] + d[6];         // rare + big (both phases)
         out[5] = d[7];                // resolve
+        for (int sl = 0; sl < 6; ++sl)
+            if (!(c.slots & (1u << sl))) out[sl] = 0.0f;      // (a neighbour's events may have bracketed it by chance)
         TOPO_HIP_TRY(hipEventElapsedTime(&out[6], ev_[0], ev_[8]));
     }
     if (load_timed_) {

@@ -56,6 +56,7 @@ class TerrainRenderer {
     int get_timings(float out[TOPO_TIMING_SLOTS]);
     int get_counters(uint32_t out[6]);
     int set_occlusion_split(float metres);
+    int set_timing_slots(uint32_t mask);
     int read_normals(int32_t lat, int32_t lon, uint8_t* out);
     int geotiff_to_device(const uint8_t* bytes, size_t n, float** d_heights, uint32_t* w, uint32_t* h, float rp[2], float mp[2], float ps[2]);
     int geotiff_decode(const uint8_t* bytes, size_t n, float* heights_out, size_t capacity);
@@ -92,6 +93,7 @@ class TerrainRenderer {
     bool table_dirty_ = true;
     int lds_rows_ = 16;
     uint32_t big_cap_cfg_ = 0, rare_cap_cfg_ = 0;
+    uint32_t timing_slots_ = 0x3Fu;        // topo_set_timing_slots: which per-kernel durations to measure
     float occlusion_split_m_ = 90000.0f;   // flat optimum 60..120 km at c4 (profiles/README.md)
 
     hipStream_t own_stream_ = nullptr, stream_ = nullptr;
@@ -107,6 +109,7 @@ class TerrainRenderer {
         hipEvent_t ev[kNumEvents] = {};
         hipEvent_t done = nullptr;
         bool timed = false, pending = false;
+        uint32_t ev_recorded = 0, slots = 0;  // which of ev[] the last frame recorded, for which timing slots
         void* d_vis = nullptr;      size_t cap_vis = 0;
         void* d_dirty = nullptr;    size_t cap_dirty = 0;   // one mark per 64 visibility keys (topo_kernels.hip: struct Vis)
         void* d_work = nullptr;     size_t cap_work = 0;

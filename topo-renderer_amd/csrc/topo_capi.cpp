@@ -128,6 +128,11 @@ int topo_get_timings(topo_ctx* ctx, float out_ms[TOPO_TIMING_SLOTS]) {
     TOPO_CALL(ctx->r->get_timings(out_ms));
 }
 
+int topo_set_timing_slots(topo_ctx* ctx, uint32_t slot_mask) {
+    TOPO_GUARD(ctx);
+    TOPO_CALL(ctx->r->set_timing_slots(slot_mask));
+}
+
 int topo_set_occlusion_split(topo_ctx* ctx, float metres) {
     TOPO_GUARD(ctx);
     return ctx->r->set_occlusion_split(metres);
