@@ -952,7 +952,7 @@ __global__ __launch_bounds__(256) void k_raster_big(FrameParams P) {
 #define TOPO_RESOLVE_ROWS 16
 #endif
 #ifndef TOPO_RESOLVE_WGS
-#define TOPO_RESOLVE_WGS 5
+#define TOPO_RESOLVE_WGS 6
 #endif
 constexpr int kResolveRows = TOPO_RESOLVE_ROWS;
 __global__ __launch_bounds__(256, TOPO_RESOLVE_WGS) void k_resolve(FrameParams P, OutputParams O) {
