@@ -4,7 +4,7 @@
 import collections, os, re, subprocess, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(R, "topo-renderer_amd", "csrc", "topo_kernels.hip")
-flags = "--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -gline-tables-only --cuda-device-only -Wno-pass-failed".split()
+flags = "--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -gline-tables-only --cuda-device-only -Wno-pass-failed".split()
 subprocess.check_call(["/opt/rocm/bin/hipcc", *flags, "-c", "-o", "/tmp/tk_dev.o", src])
 subprocess.check_call(["/opt/rocm/lib/llvm/bin/clang-offload-bundler", "--unbundle", "--type=o", "--input=/tmp/tk_dev.o",
                        "--targets=hip-amdgcn-amd-amdhsa--gfx950", "--output=/tmp/tk_gfx950.o"])
