@@ -349,7 +349,8 @@ __global__ __launch_bounds__(256) void k_cull(FrameParams P) {
             const double cy = (double)m[1] * px + (double)m[5] * py + (double)m[9] * pz + (double)m[13];
             const double cz = (double)m[2] * px + (double)m[6] * py + (double)m[10] * pz + (double)m[14];
             const double cw = (double)m[3] * px + (double)m[7] * py + (double)m[11] * pz + (double)m[15];
-            const double sx = (cx / cw * 0.5 + 0.5) * (double)P.W, sy = (0.5 - cy / cw * 0.5) * (double)P.H;
+            const double icw = 1.0 / cw;      // one f64 division per corner (the +-2 px margin dwarfs the extra rounding)
+            const double sx = (cx * icw * 0.5 + 0.5) * (double)P.W, sy = (0.5 - cy * icw * 0.5) * (double)P.H;
             bxlo = sx < bxlo ? sx : bxlo; bxhi = sx > bxhi ? sx : bxhi;
             bylo = sy < bylo ? sy : bylo; byhi = sy > byhi ? sy : byhi;
             if (cw < wmin) { wmin = cw; zclip_at_wmin = cz; }
@@ -358,7 +359,7 @@ __global__ __launch_bounds__(256) void k_cull(FrameParams P) {
         // hull its minimum sits at the corner with the smallest w.  The real pipeline computes z_clip and w as f32
         // fma chains over ~6.4e6-sized terms: each carries up to ~1 (metre-sized clip units) of cancellation noise,
         // i.e. z_ndc is only good to ~2 / w.  Shave 8 / w.
-        const double zmin = zclip_at_wmin / wmin - 8.0 / wmin;
+        const double zmin = (zclip_at_wmin - 8.0) / wmin;
         if (!(wmin > 1000.0 && zmin > 0.0 && zmin < 1.0)) {
             emit_near(P, view, rank, blk);          // no usable bound: rasterise it with the near blocks
             continue;
