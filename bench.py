@@ -163,18 +163,15 @@ def main():
     for _ in range(max(1, args.warmup)):       # first launches, buffer growth
         step()
     fence()
-    detail = {k: 0.0 for k in KERNELS + ("total",)}
-    n_detail = 0
-    for _ in range(5 + depth_frames):
+    samples = []
+    for _ in range(7 + depth_frames):
         step()
         tm = r.timings()
         if tm["total"] > 0.0:
-            n_detail += 1
-            for k in detail:
-                detail[k] += tm[k] * (per if world > 1 else 1)
+            samples.append({k: tm[k] * (per if world > 1 else 1) for k in KERNELS + ("total",)})
     fence()
-    for k in detail:
-        detail[k] /= max(1, n_detail)
+    n_detail = len(samples)
+    detail = {k: (sorted(smp[k] for smp in samples)[n_detail // 2] if n_detail else 0.0) for k in KERNELS + ("total",)}   # medians
     dom = max(("resolve", "raster", "raster_big"), key=lambda k: detail[k])
     r.set_timing_slots((dom,))
     for _ in range(args.warmup):
@@ -267,7 +264,7 @@ def main():
         "per_kernel": per_kernel,
         "kernel_ms": {k: round(v, 4) for k, v in kernel_ms.items()},
         "kernel_ms_note": f"'{dom}' and 'total': HIP events in the timed region (only those events are recorded there); the other "
-                          f"kernels: a separate pass of {n_detail} frames with all timing events on (total then {round(detail['total'], 4)} ms)",
+                          f"kernels: medians of a separate pass of {n_detail} frames with all timing events on (total then {round(detail['total'], 4)} ms)",
         "load_ms": round(load_ms, 4),
         "load_GBps": round(8.0 * n_tiles * TILE * TILE / (load_ms / 1e3) / 1e9, 1) if load_ms > 0 else None,
         "hbm_read_roofline_frac_frame": round((4.0 * n_tiles * TILE * TILE / (ms_per_step / 1e3) / 1e9) / HBM_PEAK_GBPS, 5),

@@ -488,10 +488,10 @@ struct FragList {
 };
 
 #ifndef TOPO_INLANE_ROWS
-#define TOPO_INLANE_ROWS 4
+#define TOPO_INLANE_ROWS 5
 #endif
 #ifndef TOPO_INLANE_COLS
-#define TOPO_INLANE_COLS 16
+#define TOPO_INLANE_COLS 24
 #endif
 constexpr int32_t kInlaneRows = TOPO_INLANE_ROWS, kInlaneCols = TOPO_INLANE_COLS;
 
