@@ -90,6 +90,9 @@ const char* topo_last_error(topo_ctx* ctx);
 /* ---- additive entry points (no reference counterpart) ------------------------------------------------- */
 
 /* As topo_add_terrain with `heights` already in device memory (device-to-device copy). */
+/* topo_render with device outputs: the frame of the last topo_update into rgba_dev / depth_dev (depth nullable), in stream
+ * order on the context's stream; no host copy. */
+int topo_render_device(topo_ctx* ctx, uint8_t* rgba_dev, size_t rgba_pitch, float* depth_dev, size_t depth_pitch);
 int topo_add_terrain_device(topo_ctx* ctx, int32_t lat_deg, int32_t lon_deg, const float* heights_dev, uint32_t w,
                             uint32_t h, const float raster_point[2], const float model_point[2],
                             const float pixel_scale[2]);
@@ -172,6 +175,14 @@ int topo_read_normals(topo_ctx* ctx, int32_t lat_deg, int32_t lon_deg, uint8_t* 
  * render/data.rs:44-58, data/camera.rs:44-53,97-128 (glam 0.31 arithmetic restated in f32). */
 void topo_camera_uniforms(const float eye[3], float yaw, float pitch, float fov_y, float width, float height,
                           float sun_theta_deg, float sun_phi_deg, int32_t view_mode, topo_uniforms* out);
+/* The cameras of a 360-degree strip of n_sectors perspective sectors (no reference counterpart: the
+ * reference renders one perspective view).  Sector k looks at yaw0 - k * 360/n degrees -- the reference's yaw grows
+ * counter-clockwise seen from above (Camera::direction, camera.rs:101-109), so the strip reads left to right -- with
+ * the vertical field of view that makes every sector 360/n degrees wide: 2 atan(tan(180/n deg) * sector_h / sector_w)
+ * (topo_sector_fov_y, radians).  Writes n_sectors Uniforms blocks, ready for topo_render_views_device. */
+float topo_sector_fov_y(uint32_t sector_w, uint32_t sector_h, uint32_t n_sectors);
+void topo_panorama_uniforms(const float eye[3], float yaw0, float pitch, uint32_t sector_w, uint32_t sector_h,
+                            float sun_theta_deg, float sun_phi_deg, int32_t view_mode, uint32_t n_sectors, topo_uniforms* out);
 /* TerrainUniforms::new(coordinate_transform, (width, height)) -> 96 bytes (raster_point, model_point, pixel_scale,
  * size, normal_to_world_rot column-major mat4)                              render/data.rs:113-151 */
 void topo_terrain_uniforms(const float raster_point[2], const float model_point[2], const float pixel_scale[2],

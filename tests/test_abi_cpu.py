@@ -165,3 +165,17 @@ def test_to_model_to_raster_and_height_lookup(topo):
         want = float(hts.reshape(-1)[idx]) if idx < w * h else None
         assert ct.height_value_at(hts, lon, lat) == want
     assert ct.height_value_at(hts, float("nan"), 47.5) == float(hts[int((f(47.5) - f(48.0)) / -ct.pixel_scale[1]), 0])
+
+
+def test_panorama_uniforms_are_the_sector_cameras(topo):
+    """topo_panorama_uniforms = camera_uniforms of each sector: yaw0 - k * 360/n degrees (f32 inputs, f64 sector arithmetic),
+    vertical FOV 2 atan(tan(180/n deg) * h / w)."""
+    eye = topo.geometry_transform(1500.0, 15.3, 45.2)
+    for n, (w, h) in ((8, (2048, 4096)), (8, (128, 256)), (4, (300, 200))):
+        got = topo.panorama_uniforms(eye, 0.3, w, h, 15.3, 45.2, 1, n_sectors=n, pitch=0.1)
+        fov = 2.0 * math.atan(math.tan(math.pi / n) * h / w)
+        assert abs(float(topo.lib().topo_sector_fov_y(w, h, n)) - fov) < 1e-6
+        yaw0 = float(np.float32(0.3))
+        for k in range(n):
+            want = topo.camera_uniforms(eye, yaw0 - k * (2.0 * math.pi / n), float(np.float32(0.1)), fov, w, h, 15.3, 45.2, 1)
+            assert np.array_equal(got[k].view(np.uint32), want.view(np.uint32)), (n, k)

@@ -661,3 +661,22 @@ def test_timing_slots_select_events(topo, orc):
                 assert tm[k] > 0.0, (names, k)
             else:
                 assert tm[k] == 0.0, (names, k)
+
+
+def test_render_device_equals_render(topo, orc):
+    """topo_render_device (device outputs, stream-ordered) gives the bytes topo_render copies to the host; a padded pitch works."""
+    import torch
+    sc = Scene(64, 1, 2, eye_dh=70)
+    g, o = both(topo, orc, 100, 60)
+    sc.load(g)
+    sc.load(o)
+    u, pu = sc.uniforms(100, 60, 25, 8, 65, 0), topo.post_uniforms(100, 60)
+    g.update(100, 60, u, pu)
+    o.update(100, 60, u, pu)
+    want = o.render()
+    rgba = torch.zeros((60, 128, 4), dtype=torch.uint8, device="cuda")       # pitch 512 B > 400 B
+    depth = torch.zeros((60, 128), dtype=torch.float32, device="cuda")
+    g.render_device(rgba.data_ptr(), 128 * 4, depth.data_ptr(), 128 * 4)
+    g.synchronize()
+    assert_same_frame((rgba[:, :100].cpu().numpy(), depth[:, :100].cpu().numpy()), want, "topo_render_device")
+    assert int(rgba[:, 100:].max()) == 0 and float(depth[:, 100:].abs().max()) == 0.0      # the padding is not touched

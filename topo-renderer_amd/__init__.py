@@ -110,6 +110,9 @@ def lib():
             "topo_locations_range": (u32, [f32, f32, f32, vp, u32]),
             "topo_coordinate_transform": (C.c_int, [vp, u32, vp, u32, vp, vp, vp, vp]),
             "topo_geotiff_info": (C.c_int, [vp, sz, vp, vp, vp, vp, vp]),
+            "topo_sector_fov_y": (f32, [u32, u32, u32]),
+            "topo_panorama_uniforms": (None, [vp, f32, f32, u32, u32, f32, f32, i32, u32, vp]),
+            "topo_render_device": (C.c_int, [vp, vp, sz, vp, sz]),
             "topo_geotiff_decode": (C.c_int, [vp, vp, sz, vp, sz]),
             "topo_add_terrain_geotiff": (C.c_int, [vp, i32, i32, vp, sz]),
             "topo_to_model": (None, [vp, vp, vp, f32, f32, vp]),
@@ -241,9 +244,10 @@ def panorama_uniforms(eye, yaw0, sector_w, sector_h, sun_theta_deg, sun_phi_deg,
     """The n_sectors reference cameras of a 360-degree strip.  The reference's yaw grows counter-clockwise seen
     from above (Camera::direction, camera.rs:101-109), so sector k looks at yaw0 - k*(360/n) degrees: the strip then
     reads left to right, each sector's right edge meeting the next one's left edge."""
-    fov = sector_fov_y(sector_w, sector_h, n_sectors)
-    return [camera_uniforms(eye, yaw0 - k * (2.0 * math.pi / n_sectors), pitch, fov, sector_w, sector_h,
-                            sun_theta_deg, sun_phi_deg, view_mode) for k in range(n_sectors)]
+    out = np.zeros((n_sectors, 40), dtype=np.float32)
+    e = np.ascontiguousarray(eye, dtype=np.float32)
+    lib().topo_panorama_uniforms(_p(e), yaw0, pitch, sector_w, sector_h, sun_theta_deg, sun_phi_deg, view_mode, n_sectors, _p(out))
+    return [out[k].copy() for k in range(n_sectors)]
 
 
 # ---- the TerrainRenderer mirror ------------------------------------------------------------------------
@@ -325,6 +329,10 @@ class TerrainRenderer:
         self._check(lib().topo_add_terrain_geotiff(self._h, lat_deg, lon_deg, _p(buf), buf.size))
         w, h, _ = geotiff_info(data)
         self.tile_size = (w, h)
+
+    def render_device(self, rgba_ptr: int, rgba_pitch: int, depth_ptr: int = 0, depth_pitch: int = 0):
+        """topo_render_device: the frame of the last update() into device buffers."""
+        self._check(lib().topo_render_device(self._h, C.c_void_p(rgba_ptr), rgba_pitch, C.c_void_p(depth_ptr) if depth_ptr else None, depth_pitch))
 
     def recompute_normals(self):
         self._check(lib().topo_recompute_normals(self._h))

@@ -473,6 +473,20 @@ int TerrainRenderer::render_frame(FrameCtx& c, hipStream_t stream, uint32_t n, c
     return TOPO_OK;
 }
 
+int TerrainRenderer::render_device(uint8_t* rgba_dev, size_t rgba_pitch, float* depth_dev, size_t depth_pitch) {
+    if (!rgba_dev) return fail(TOPO_ERR_INVALID, "rgba_dev is null");
+    if (!have_uniforms_) return fail(TOPO_ERR_INVALID, "topo_update has not been called");
+    if (rgba_pitch < (size_t)W_ * 4 || (depth_dev && depth_pitch < (size_t)W_ * 4)) return fail(TOPO_ERR_INVALID, "pitch smaller than a row");
+    OutputParams o{};
+    o.rgba = rgba_dev;
+    o.rgba_view_stride = rgba_pitch * H_;
+    o.rgba_pitch = rgba_pitch;
+    o.depth = depth_dev;
+    o.depth_view_stride = depth_pitch * H_;
+    o.depth_pitch = depth_pitch;
+    return render_views_device(1, &uniforms_, W_, H_, o);
+}
+
 // render (terrain_renderer.rs:365-452) + depth copy (render_engine.rs:219-249), host outputs.
 int TerrainRenderer::render(uint8_t* rgba, size_t rgba_pitch, float* depth, size_t depth_pitch) {
     if (!rgba) return fail(TOPO_ERR_INVALID, "rgba_out is null");

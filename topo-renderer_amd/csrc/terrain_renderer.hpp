@@ -45,6 +45,7 @@ class TerrainRenderer {
     int update(uint32_t w, uint32_t h, const topo_uniforms* u, const topo_post_uniforms* pu);
     int render(uint8_t* rgba, size_t rgba_pitch, float* depth, size_t depth_pitch);
     int render_views_device(uint32_t n, const topo_uniforms* views, uint32_t w, uint32_t h, const OutputParams& out);
+    int render_device(uint8_t* rgba_dev, size_t rgba_pitch, float* depth_dev, size_t depth_pitch);
     int recompute_normals();
 
     int set_stream(hipStream_t s);

@@ -1,4 +1,5 @@
 // topo_capi.cpp -- the extern "C" boundary (include/topo_hip.h) over topo::TerrainRenderer.
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <new>
@@ -183,6 +184,23 @@ int topo_probe_div(topo_ctx* ctx, int32_t kind, const float* x, const float* y, 
 void topo_camera_uniforms(const float eye[3], float yaw, float pitch, float fov_y, float width, float height,
                           float sun_theta_deg, float sun_phi_deg, int32_t view_mode, topo_uniforms* out) {
     topo::camera_uniforms(eye, yaw, pitch, fov_y, width, height, sun_theta_deg, sun_phi_deg, view_mode, out);
+}
+
+float topo_sector_fov_y(uint32_t sector_w, uint32_t sector_h, uint32_t n_sectors) {
+    return (float)(2.0 * atan(tan(3.14159265358979323846 / (double)n_sectors) * (double)sector_h / (double)sector_w));
+}
+
+void topo_panorama_uniforms(const float eye[3], float yaw0, float pitch, uint32_t sector_w, uint32_t sector_h, float sun_theta_deg,
+                            float sun_phi_deg, int32_t view_mode, uint32_t n_sectors, topo_uniforms* out) {
+    const double fov = 2.0 * atan(tan(3.14159265358979323846 / (double)n_sectors) * (double)sector_h / (double)sector_w);
+    for (uint32_t k = 0; k < n_sectors; ++k)
+        topo::camera_uniforms(eye, (float)((double)yaw0 - (double)k * (2.0 * 3.14159265358979323846 / (double)n_sectors)), pitch, (float)fov,
+                              (float)sector_w, (float)sector_h, sun_theta_deg, sun_phi_deg, view_mode, out + k);
+}
+
+int topo_render_device(topo_ctx* ctx, uint8_t* rgba_dev, size_t rgba_pitch, float* depth_dev, size_t depth_pitch) {
+    TOPO_GUARD(ctx);
+    TOPO_CALL(ctx->r->render_device(rgba_dev, rgba_pitch, depth_dev, depth_pitch));
 }
 
 void topo_terrain_uniforms(const float rp[2], const float mp[2], const float ps[2], uint32_t w, uint32_t h, float out[24]) {
