@@ -1,6 +1,7 @@
 """The C-ABI library loads, exports every symbol include/topo_hip.h declares, refuses to work without a GPU,
 and its host-side helpers (the reference's CPU math) agree with the oracle's independent restatement."""
 import math
+import os
 import re
 import subprocess
 
@@ -179,3 +180,19 @@ def test_panorama_uniforms_are_the_sector_cameras(topo):
         for k in range(n):
             want = topo.camera_uniforms(eye, yaw0 - k * (2.0 * math.pi / n), float(np.float32(0.1)), fov, w, h, 15.3, 45.2, 1)
             assert np.array_equal(got[k].view(np.uint32), want.view(np.uint32)), (n, k)
+
+
+def test_header_is_plain_c(topo, tmp_path):
+    """include/topo_hip.h is C (not only C++): a C99 harness compiles against it, links libtopo_hip.so and runs its
+    host-side entry points; topo_create fails cleanly on a box without a HIP device."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "abi_harness")
+    libdir = os.path.dirname(topo.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "abi_harness.c"),
+                           "-o", exe, "-L", libdir, "-ltopo_hip", "-Wl,-rpath," + libdir, "-lm"])
+    env = dict(os.environ)
+    torch_lib = os.path.join(os.path.dirname(__import__("torch").__file__), "lib")
+    env["LD_LIBRARY_PATH"] = torch_lib + ":/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+    out = subprocess.run([exe], env=env, capture_output=True, text=True)
+    assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
+    assert "abi harness ok" in out.stdout
