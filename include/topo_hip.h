@@ -30,7 +30,8 @@ typedef enum topo_status {
     TOPO_ERR_UNSUPPORTED = -2, /* valid in the reference but outside this path (pixelize_n < 99.99999, format) */
     TOPO_ERR_HIP = -3,         /* a HIP runtime call failed (no device, out of memory, launch failure) */
     TOPO_ERR_NOT_FOUND = -4,   /* no such tile */
-    TOPO_ERR_CAPACITY = -5     /* draw-order id space exhausted (too many / too large tiles) */
+    TOPO_ERR_CAPACITY = -5     /* draw-order id space exhausted (too many / too large tiles), or a frame overflowed its
+                                * rare-triangle queue and is incomplete (see topo_join) */
 } topo_status;
 
 /* wgpu::TextureFormat::Rgba8UnormSrgb -- the only colour format of the headless path (render_engine.rs:77-84
@@ -89,10 +90,11 @@ const char* topo_last_error(topo_ctx* ctx);
 
 /* ---- additive entry points (no reference counterpart) ------------------------------------------------- */
 
-/* As topo_add_terrain with `heights` already in device memory (device-to-device copy). */
 /* topo_render with device outputs: the frame of the last topo_update into rgba_dev / depth_dev (depth nullable), in stream
- * order on the context's stream; no host copy. */
+ * order on the context's stream; no host copy.  Asynchronous: the frame's status is reported by the call that waits
+ * for it (topo_join / topo_synchronize, or topo_frame_status). */
 int topo_render_device(topo_ctx* ctx, uint8_t* rgba_dev, size_t rgba_pitch, float* depth_dev, size_t depth_pitch);
+/* As topo_add_terrain with `heights` already in device memory (device-to-device copy). */
 int topo_add_terrain_device(topo_ctx* ctx, int32_t lat_deg, int32_t lon_deg, const float* heights_dev, uint32_t w,
                             uint32_t h, const float raster_point[2], const float model_point[2],
                             const float pixel_scale[2]);
@@ -134,14 +136,23 @@ int topo_synchronize(topo_ctx* ctx);
  * complete after topo_join (waits for the frames in flight) or topo_synchronize.  Depth 1 (default): everything runs
  * in order on the context's stream.  topo_render (host outputs) always waits for its frame. */
 int topo_set_pipeline_depth(topo_ctx* ctx, int32_t depth);
+/* Waits for every frame in flight.  A frame's status word is per frame; if one of the frames waited for overflowed its
+ * rare-triangle queue (triangles were dropped: its outputs are incomplete) topo_join -- and likewise topo_synchronize --
+ * returns TOPO_ERR_CAPACITY, once per such frame; the frames after it are unaffected.  (topo_render, the synchronous
+ * entry point, never hands out such a frame: it grows the queue and renders the frame again.) */
 int topo_join(topo_ctx* ctx);
+/* Status of the most recent frame that has been waited for (waits for the frames in flight first):
+ * out[0] = status bits (bit 0 big-triangle queue overflowed: handled exactly, slower; bit 1 rare-triangle queue overflowed:
+ * frame incomplete; bit 2 bounds violation, only ever set by the TOPO_BOUNDS_CHECK build libtopo_hip_check.so),
+ * out[1] = site tag and out[2], out[3] = low/high word of the offending value of the first bounds violation. */
+int topo_frame_status(topo_ctx* ctx, uint32_t out[4]);
 
 /* LDS tile height (output rows per workgroup: 4, 8, 16, 32 or 64) of the interior-normals kernel. */
 int topo_set_normals_lds_rows(topo_ctx* ctx, int rows);
 
 /* Two-phase occlusion filter: blocks whose nearest possible view depth exceeds `metres` are rastered only if some
  * pixel of their conservative footprint is not already covered by nearer terrain (exact: a dropped block cannot
- * win a pixel).  Default 60 000 m; 0 turns the filter off (one phase, every frustum-surviving block rastered). */
+ * win a pixel).  Default 90 000 m; 0 turns the filter off (one phase, every frustum-surviving block rastered). */
 int topo_set_occlusion_split(topo_ctx* ctx, float metres);
 
 /* Per-kernel durations (ms, HIP events on the context's stream) of the last topo_render* call:
@@ -155,15 +166,17 @@ int topo_get_timings(topo_ctx* ctx, float out_ms[TOPO_TIMING_SLOTS]);
  * read 0, the total [6] is always measured. */
 int topo_set_timing_slots(topo_ctx* ctx, uint32_t slot_mask);
 
-/* Counters of the last topo_render* call: [0] near blocks rastered, [1] big-triangle items, [2] status bits
+/* Counters of the last topo_render* call: [0] near blocks rastered, [1] big-triangle items, [2] that frame's status bits
  * (bit 0: big-triangle queue overflowed -- handled in-lane, slower, still exact; bit 1: rare-triangle queue
- * overflowed -- triangles dropped, frame invalid; topo_render returns TOPO_ERR_CAPACITY), [3] rare triangles
+ * overflowed -- triangles dropped, frame incomplete: see topo_join), [3] rare triangles
  * (>= 64 px across or near-clipped), [4] far blocks occlusion-tested, [5] far blocks that survived the test. */
 int topo_get_counters(topo_ctx* ctx, uint32_t out[6]);
 
-/* Test hook: capacities (entries) of the big-triangle and rare-triangle queues; 0 restores the default (4 Mi each).
- * Lets the tests drive the overflow paths: a full big queue is handled exactly (slower), a full rare queue drops
- * triangles and makes topo_render fail with TOPO_ERR_CAPACITY. */
+/* Test hook: capacities (entries) of the big-triangle and rare-triangle queues; 0 restores the default (4 Mi each,
+ * the rare queue growing on demand under topo_render).  Lets the tests drive the overflow paths: a full big queue is
+ * handled exactly (slower); a full rare queue of an explicitly set capacity drops triangles and makes the call that waits
+ * for the frame fail with TOPO_ERR_CAPACITY.  rare_cap with bit 31 set = "start at (rare_cap & 0x7FFFFFFF) entries and
+ * grow on demand", i.e. the default behaviour from a small starting size. */
 int topo_debug_set_queue_caps(topo_ctx* ctx, uint32_t big_cap, uint32_t rare_cap);
 
 /* Test accessor: the tile's Rgba8Unorm normal texture, w*h*4 bytes, host pointer. */

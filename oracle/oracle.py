@@ -38,6 +38,7 @@ def lib():
         L.oracle_render_views.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t,
                                           C.c_void_p, C.c_size_t, C.c_size_t, C.c_int]
         L.oracle_read_normals.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+        L.oracle_render_winners.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_camera_uniforms.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                              C.c_float, C.c_float, C.c_int32, C.c_void_p]
         L.oracle_terrain_uniforms.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
@@ -147,6 +148,15 @@ class OracleRenderer:
         pre = np.empty((h, w, 4), np.uint8) if want_pre_post else None
         self._check(lib().oracle_render(self._h, _p(rgba), w * 4, _p(depth), w * 4, _p(pre) if pre is not None else None))
         return (rgba, depth, pre) if want_pre_post else (rgba, depth)
+
+    def render_winners(self):
+        """(depth (h,w) f32, winner (h,w) u32): winner = tile rank in draw order * 2(w-1)(h-1) + index-buffer triangle,
+        0xFFFFFFFF where nothing was drawn.  Bookkeeping for oracle/ray_check.py."""
+        w, h = self.size
+        depth = np.empty((h, w), np.float32)
+        win = np.empty((h, w), np.uint32)
+        self._check(lib().oracle_render_winners(self._h, _p(depth), _p(win)))
+        return depth, win
 
     def render_views(self, uniforms_list, threads=1):
         """n frames -> rgba (n,h,w,4), depth (n,h,w)"""

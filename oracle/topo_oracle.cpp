@@ -414,6 +414,10 @@ struct Frame {
     std::vector<float> depth;     /* Depth32Float, clear 1.0 (terrain_renderer.rs:392) */
     std::vector<uint8_t> color;   /* render_texture, Rgba8UnormSrgb */
     std::vector<uint8_t> final_;  /* surface, Rgba8UnormSrgb */
+    /* bookkeeping for oracle/ray_check.py only (not part of any reference resource): the draw that owns each pixel,
+     * (tile rank in draw order) * 2(w-1)(h-1) + index-buffer triangle; 0xFFFFFFFF = cleared */
+    std::vector<uint32_t> winner;
+    uint32_t cur_draw = 0;
 };
 
 void store_color(Frame& f, size_t p, const float c[4]) {
@@ -519,6 +523,7 @@ void raster_triangle(Frame& f, const Uniforms& u, const VSOut& v0, const VSOut& 
             float c[4];
             fs_main(u, (float)px + 0.5f, (float)py + 0.5f, wpos, wnrm, c);
             f.depth[p] = z;
+            if (!f.winner.empty()) f.winner[p] = f.cur_draw;
             store_color(f, p, c);
         }
 }
@@ -579,7 +584,7 @@ void draw_triangle(Frame& f, const Uniforms& u, const PV& pa, const PV& pb, cons
 }
 
 /* generate_indices: render_buffer.rs:191-219 (vertex index = i*h + j <-> texel (x=i, y=j), :185-189) */
-void draw_tile(Frame& f, const Uniforms& u, const Tile& t) {
+void draw_tile(Frame& f, const Uniforms& u, const Tile& t, uint32_t draw_base = 0) {
     /* post-transform vertex cache (vs_main is a pure function of the vertex) */
     std::vector<PV> vs((size_t)t.w * t.h);
     for (uint32_t i = 0; i < t.w; ++i)
@@ -587,11 +592,14 @@ void draw_tile(Frame& f, const Uniforms& u, const Tile& t) {
     for (uint32_t i = 0; i + 1 < t.w; ++i)
         for (uint32_t j = 0; j + 1 < t.h; ++j) {
             size_t index = (size_t)i * t.h + j, next = (size_t)(i + 1) * t.h + j;
+            f.cur_draw = draw_base + (uint32_t)(((size_t)i * (t.h - 1) + j) * 2);
             if ((i + j) % 2 == 0) {
                 draw_triangle(f, u, vs[index], vs[index + 1], vs[next + 1]);
+                ++f.cur_draw;
                 draw_triangle(f, u, vs[next + 1], vs[next], vs[index]);
             } else {
                 draw_triangle(f, u, vs[index], vs[index + 1], vs[next]);
+                ++f.cur_draw;
                 draw_triangle(f, u, vs[next + 1], vs[next], vs[index + 1]);
             }
         }
@@ -647,7 +655,11 @@ void render_frame(const Oracle& o, const Uniforms& u, Frame& f) {
     f.final_.resize(P * 4);
     const float clear[4] = {(float)0.0, (float)0.71, (float)0.885, (float)1.0}; /* terrain_renderer.rs:379-384 */
     for (size_t p = 0; p < P; ++p) store_color(f, p, clear);
-    for (const auto& kv : o.tiles) draw_tile(f, u, *kv.second); /* BTreeMap order, :407-420 */
+    uint32_t rank = 0;
+    for (const auto& kv : o.tiles) {   /* BTreeMap order, :407-420 */
+        draw_tile(f, u, *kv.second, rank * 2u * (kv.second->w - 1) * (kv.second->h - 1));
+        ++rank;
+    }
     post_pass(f);
 }
 
@@ -753,6 +765,17 @@ int oracle_render_views(void* p, uint32_t n, const void* uniforms160xn, uint8_t*
         copy_out(f, rgba ? rgba + (size_t)v * rgba_view_stride : nullptr, rgba_pitch,
                  depth ? (float*)((uint8_t*)depth + (size_t)v * depth_view_stride) : nullptr, depth_pitch, nullptr);
     }
+    return 0;
+}
+
+/* As oracle_render, additionally reporting which draw owns each pixel (ray_check.py compares it with a ray cast). */
+int oracle_render_winners(void* p, float* depth, uint32_t* winner) {
+    Oracle& o = *(Oracle*)p;
+    o.frame.winner.assign((size_t)o.W * o.H, 0xFFFFFFFFu);
+    render_frame(o, o.u, o.frame);
+    memcpy(depth, o.frame.depth.data(), (size_t)o.W * o.H * 4);
+    memcpy(winner, o.frame.winner.data(), (size_t)o.W * o.H * 4);
+    o.frame.winner.clear();
     return 0;
 }
 

@@ -209,6 +209,72 @@ void emul_visible_peaks(const float* proj, uint32_t W, uint32_t H, const float* 
     }
 }
 
+// ---- lane bodies of the raster kernels under a bounds-checking sink ---------------------------------------------------
+// The sink the kernels use is `atomicMin(vis + pix)` + `dirty[(view base + pix) >> 6] = 1`: an index outside the target
+// is a wild write on the GPU.  Here every fragment is checked instead: inside the target, inside the item's region (big
+// items), emitted at most once per (item, pixel).  Returns the number of violations; keys[] (W*H, caller-initialised to
+// kVisClear) receives the min of the emitted keys, n_frag their count.
+struct CheckSink {
+    uint64_t* keys; std::vector<uint8_t> seen; int W, H, rx, ry; int violations = 0; uint32_t n = 0;
+    CheckSink(uint64_t* k, int w, int h, int rx_, int ry_) : keys(k), seen((size_t)w * h, 0), W(w), H(h), rx(rx_), ry(ry_) {}
+    void operator()(size_t pix, uint64_t key) {
+        if (pix >= (size_t)W * H) { ++violations; return; }
+        const int px = (int)(pix % W), py = (int)(pix / W);
+        if (rx >= 0 && (px < rx * 64 || px > rx * 64 + 63 || py < ry * 64 || py > ry * 64 + 63)) ++violations;
+        if (seen[pix]) ++violations;
+        seen[pix] = 1;
+        if (key < keys[pix]) keys[pix] = key;
+        ++n;
+    }
+};
+
+int emul_big_item(const int32_t* X, const int32_t* Y, const float* z, uint32_t id, int W, int H, int rx, int ry, uint64_t* keys,
+                  uint32_t* n_frag, int* was_medium) {
+    CheckSink sink(keys, W, H, rx, ry);
+    const bool medium = spans_fit_int32(X[0], Y[0], X[1], Y[1], X[2], Y[2]);
+    *was_medium = medium ? 1 : 0;
+    for (uint32_t lane = 0; lane < 64; ++lane) {
+        if (medium)
+            big_medium_lane(X, Y, z, id, W, H, rx, ry, lane, [&](const uint32_t pix[4], const uint64_t key[4]) {
+                for (int k = 0; k < 4; ++k)
+                    if (key[k] != kVisClear) sink(pix[k], key[k]);     // the contract: pix[k] is only meaningful with a key
+            });
+        else
+            big_giant_lane(X, Y, z, id, W, H, rx, ry, lane, [&](size_t pix, uint64_t key) { sink(pix, key); });
+    }
+    *n_frag = sink.n;
+    return sink.violations;
+}
+
+int emul_raster_rows(const int32_t* X, const int32_t* Y, const float* z, uint32_t id, int W, int H, uint64_t* keys, uint32_t* n_frag) {
+    CheckSink sink(keys, W, H, -1, -1);
+    if (!spans_fit_int32(X[0], Y[0], X[1], Y[1], X[2], Y[2])) return -1;
+    const int32_t area2 = (X[1] - X[0]) * (Y[2] - Y[0]) - (Y[1] - Y[0]) * (X[2] - X[0]);
+    if (area2 < 0)      // classify_small only lists front-facing triangles
+        raster_rows(W, H, X[0], Y[0], X[1], Y[1], X[2], Y[2], z[0], z[1], z[2], id, [&](uint32_t pix, uint64_t key) { sink(pix, key); });
+    *n_frag = sink.n;
+    return sink.violations;
+}
+
+// the same triangle through triangle_setup / triangle_pixel (the generic path the oracle-parity tests pin); rx < 0: no region
+void emul_reference_triangle(const int32_t* X, const int32_t* Y, const float* z, uint32_t id, int W, int H, int rx, int ry, uint64_t* keys,
+                             uint32_t* n_frag) {
+    SVert s[3];
+    for (int k = 0; k < 3; ++k) { s[k].X = X[k]; s[k].Y = Y[k]; s[k].z = z[k]; s[k].flag = kVtxOk; }
+    TriSetup ts;
+    *n_frag = 0;
+    if (!triangle_setup(s[0], s[1], s[2], W, H, ts)) return;
+    for (int py = ts.py0; py <= ts.py1; ++py) for (int px = ts.px0; px <= ts.px1; ++px) {
+        if (rx >= 0 && (px < rx * 64 || px > rx * 64 + 63 || py < ry * 64 || py > ry * 64 + 63)) continue;
+        float zz, b[3];
+        if (triangle_pixel(ts, px, py, zz, b)) {
+            const uint64_t key = vis_key(zz, id);
+            if (key < keys[(size_t)py * W + px]) keys[(size_t)py * W + px] = key;
+            ++*n_frag;
+        }
+    }
+}
+
 float emul_from_unorm8(uint32_t c) { return from_unorm8(c); }
 
 uint64_t emul_vis_key(float z, uint32_t id) { return vis_key(z, id); }

@@ -11,10 +11,16 @@ import topo_renderer_amd as T
 class Scene:
     """A mosaic of synthetic tiles plus one viewpoint, in the insertion order of SURVEY.md 8d."""
 
-    def __init__(self, tile=64, n_lat=1, n_lon=1, lat0=45, lon0=15, vfrac=(0.5123, 0.5217), eye_dh=50.0, seed=T.synth.SEED_DEFAULT):
+    def __init__(self, tile=64, n_lat=1, n_lon=1, lat0=45, lon0=15, vfrac=(0.5123, 0.5217), eye_dh=50.0, seed=T.synth.SEED_DEFAULT,
+                 height_fn=None):
         self.tile = tile
         self.locs = T.synth.mosaic_locations(lat0, lon0, n_lat, n_lon)
-        self.heights = {loc: T.synth_tile(loc[0], loc[1], tile, tile, seed) for loc in self.locs}
+        if height_fn is None:
+            self.heights = {loc: T.synth_tile(loc[0], loc[1], tile, tile, seed) for loc in self.locs}
+        else:       # analytic relief h(lat_deg, lon_deg) sampled at the vertices (row 0 = north, tile_transform's layout)
+            x = np.arange(tile, dtype=np.float64) / tile
+            self.heights = {loc: np.ascontiguousarray(height_fn((loc[0] + 1 - x)[:, None], (loc[1] + x)[None, :]), dtype=np.float32)
+                            for loc in self.locs}
         self.vlat = lat0 + n_lat * vfrac[0]
         self.vlon = lon0 + n_lon * vfrac[1]
         tl, to = int(math.floor(self.vlat)), int(math.floor(self.vlon))

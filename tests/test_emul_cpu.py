@@ -229,3 +229,78 @@ def test_non_square_tiles_match_oracle(topo, orc, tw, th):
     e.update(W, H, u, topo.post_uniforms(W, H))
     o.update(W, H, u, topo.post_uniforms(W, H))
     assert_same_frame(e.render(), o.render(), f"{tw}x{th}")
+
+
+# ---- lane bodies of k_raster / k_raster_big under a bounds-checking sink -------------------------------------------
+def _tri_cases(rng, n, W, H):
+    """Snapped triangles (1/256 px) of every size class: sub-pixel, a few pixels, ~64 px (the int32/int64 border),
+    giants, slivers, partly and wholly off-target, degenerate, and ones hugging the target's last row/column."""
+    out = []
+    for i in range(n):
+        kind = i % 8
+        cx, cy = rng.uniform(-0.2 * W, 1.2 * W), rng.uniform(-0.2 * H, 1.2 * H)
+        size = [0.7, 3.0, 12.0, 40.0, 63.9, 200.0, 3000.0, 30.0][kind]
+        pts = np.stack([rng.uniform(-size, size, 3) + cx, rng.uniform(-size, size, 3) + cy], axis=1)
+        if kind == 7:                       # sliver: third vertex almost on the edge of the first two
+            t = rng.uniform(0, 1)
+            pts[2] = pts[0] + t * (pts[1] - pts[0]) + rng.uniform(-0.3, 0.3, 2)
+        if i % 11 == 0:                     # touch the far corner of the target
+            pts += np.array([W - 1.0, H - 1.0]) - pts[0]
+        if i % 13 == 0:
+            pts[1] = pts[0]                 # degenerate
+        X = np.rint(pts[:, 0] * 256).astype(np.int32)
+        Y = np.rint(pts[:, 1] * 256).astype(np.int32)
+        z = rng.uniform(0.0, 1.05, 3).astype(np.float32)
+        if i % 7 == 0:
+            z = rng.uniform(-0.2, 1.3, 3).astype(np.float32)       # crosses both depth clamps
+        if rng.integers(0, 2):              # both windings (back faces must emit nothing)
+            X[[1, 2]] = X[[2, 1]]; Y[[1, 2]] = Y[[2, 1]]; z[[1, 2]] = z[[2, 1]]
+        out.append((X, Y, z))
+    return out
+
+
+@pytest.mark.parametrize("W,H", [(200, 130), (64, 64), (257, 65)])
+def test_big_item_lanes_stay_in_bounds_and_match_triangle_pixel(W, H):
+    """Every BigItem a triangle can produce (one per overlapped 64x64 px region, as enqueue_big cuts it), through the
+    product's 64 lane bodies with a checking sink: no fragment outside the target or the region, none emitted twice, and
+    the keys are exactly those of triangle_setup/triangle_pixel restricted to the region."""
+    import ctypes as C
+    L = emul.lib()
+    L.emul_big_item.restype = C.c_int
+    clear = np.uint64(0x3F800000FFFFFFFF)
+    rng = np.random.default_rng(W * 1000 + H)
+    n_medium = n_giant = 0
+    for i, (X, Y, z) in enumerate(_tri_cases(rng, 260, W, H)):
+        for ry in range((H + 63) // 64):
+            for rx in range((W + 63) // 64):
+                got = np.full(W * H, clear, np.uint64)
+                ref = np.full(W * H, clear, np.uint64)
+                ng, nr, med = C.c_uint32(), C.c_uint32(), C.c_int()
+                v = L.emul_big_item(emul._p(X), emul._p(Y), emul._p(z), 2 * i, W, H, rx, ry, emul._p(got), C.byref(ng), C.byref(med))
+                L.emul_reference_triangle(emul._p(X), emul._p(Y), emul._p(z), 2 * i, W, H, rx, ry, emul._p(ref), C.byref(nr))
+                assert v == 0, f"triangle {i} region ({rx},{ry}): {v} bounds/duplicate violations"
+                assert ng.value == nr.value and np.array_equal(got, ref), f"triangle {i} region ({rx},{ry})"
+                n_medium += med.value; n_giant += 1 - med.value
+    assert n_medium > 100 and n_giant > 50
+
+
+def test_raster_rows_stays_in_bounds_and_matches_triangle_pixel():
+    import ctypes as C
+    L = emul.lib()
+    L.emul_raster_rows.restype = C.c_int
+    clear = np.uint64(0x3F800000FFFFFFFF)
+    W, H = 96, 70
+    rng = np.random.default_rng(11)
+    walked = 0
+    for i, (X, Y, z) in enumerate(_tri_cases(rng, 1200, W, H)):
+        got = np.full(W * H, clear, np.uint64)
+        ref = np.full(W * H, clear, np.uint64)
+        ng, nr = C.c_uint32(), C.c_uint32()
+        v = L.emul_raster_rows(emul._p(X), emul._p(Y), emul._p(z), 2 * i, W, H, emul._p(got), C.byref(ng))
+        if v < 0:
+            continue                        # spans >= 64 px: not a k_raster triangle
+        L.emul_reference_triangle(emul._p(X), emul._p(Y), emul._p(z), 2 * i, W, H, -1, -1, emul._p(ref), C.byref(nr))
+        assert v == 0, f"triangle {i}: {v} violations"
+        assert ng.value == nr.value and np.array_equal(got, ref), f"triangle {i}"
+        walked += ng.value > 0
+    assert walked > 100

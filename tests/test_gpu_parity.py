@@ -283,7 +283,7 @@ def test_peak_visibility_against_depth(topo, orc):
 
 def test_queue_overflow_paths(topo, orc):
     # big-triangle queue full -> the producers rasterise in place: slower, still exact, status bit 0 set;
-    # rare-triangle queue full -> triangles would be dropped: topo_render must fail loudly.
+    # rare-triangle queue full -> triangles would be dropped: topo_render must not hand that frame out.
     sc = Scene(12, 2, 2, eye_dh=60.0)
     W, H = 320, 240
     g, o = both(topo, orc, W, H)
@@ -296,13 +296,67 @@ def test_queue_overflow_paths(topo, orc):
     g.debug_set_queue_caps(16, 0)
     assert_same_frame(g.render(), ref, "big queue overflow")
     assert g.counters()["status"] & 1
-    g.debug_set_queue_caps(0, 2)
+    g.debug_set_queue_caps(0, 2)                      # an explicit capacity is not grown: the call fails loudly
     with pytest.raises(topo.TopoError) as e:
         g.render()
     assert e.value.code == topo.TOPO_ERR_CAPACITY
+    g.debug_set_queue_caps(0, 2 | 0x80000000)         # a growable queue (the default, from a tiny start): re-rendered, exact
+    assert_same_frame(g.render(), ref, "rare queue grown on demand")
+    assert g.counters()["status"] == 0 and g.counters()["rare_items"] > 2
     g.debug_set_queue_caps(0, 0)
     assert_same_frame(g.render(), ref, "defaults restored")
     assert g.counters()["status"] == 0
+
+
+def test_overflow_status_is_per_frame_on_the_async_paths(topo, orc):
+    """topo_render_device / topo_render_views_device return before the frame exists: an overflowed (incomplete) frame is
+    reported by the call that waits for it -- once -- and a complete frame after it is reported as complete."""
+    import torch
+    sc = Scene(12, 2, 2, eye_dh=60.0)
+    W, H = 320, 240
+    g, o = both(topo, orc, W, H)
+    sc.load(g)
+    sc.load(o)
+    down = sc.uniforms(W, H, 10, 35, 110, 0)                                             # near-field giants: hundreds of rare triangles
+    high = topo.geometry_transform(sc.ground + 250000.0, sc.vlon, sc.vlat)               # from 250 km up: nothing near, nothing clipped
+    up = topo.camera_uniforms(high, 0.3, np.radians(80.0), np.radians(60.0), W, H, sc.vlon, sc.vlat, 0)
+    rgba = torch.empty((H, W, 4), dtype=torch.uint8, device="cuda")
+    depth = torch.empty((H, W), dtype=torch.float32, device="cuda")
+    pu = topo.post_uniforms(W, H)
+
+    def frame(u):
+        g.update(W, H, u, pu)
+        g.render_device(rgba.data_ptr(), W * 4, depth.data_ptr(), W * 4)
+
+    g.debug_set_queue_caps(0, 2)
+    frame(down)
+    with pytest.raises(topo.TopoError) as e:
+        g.join()
+    assert e.value.code == topo.TOPO_ERR_CAPACITY
+    g.join()                                           # reported once
+    assert g.frame_status()["rare_overflow"]
+    frame(up)                                          # no rare triangles from up there: complete although the cap is still 2
+    g.synchronize()
+    st = g.frame_status()
+    assert not st["rare_overflow"] and st["status"] == 0
+    o.update(W, H, up, pu)
+    ro, do = o.render()
+    assert np.array_equal(rgba.cpu().numpy(), ro) and np.array_equal(depth.cpu().numpy().view(np.uint32), do.view(np.uint32))
+    for depth_frames in (1, 2):                        # the same through the frames-in-flight path
+        g.set_pipeline_depth(depth_frames)
+        frame(down)
+        frame(up)
+        with pytest.raises(topo.TopoError):
+            g.join()
+        frame(up)
+        g.join()
+    g.set_pipeline_depth(1)
+    g.debug_set_queue_caps(0, 0)
+    frame(down)
+    g.synchronize()
+    o.update(W, H, down, pu)
+    ro, do = o.render()
+    assert np.array_equal(rgba.cpu().numpy(), ro) and np.array_equal(depth.cpu().numpy().view(np.uint32), do.view(np.uint32))
 
 
 @pytest.mark.parametrize("tw,th", [(40, 30), (30, 40), (3, 3), (61, 16), (62, 17)])
@@ -680,3 +734,201 @@ def test_render_device_equals_render(topo, orc):
     g.synchronize()
     assert_same_frame((rgba[:, :100].cpu().numpy(), depth[:, :100].cpu().numpy()), want, "topo_render_device")
     assert int(rgba[:, 100:].max()) == 0 and float(depth[:, 100:].abs().max()) == 0.0      # the padding is not touched
+
+
+# ---- round 2: the knobs, configs and entry points round 1 left without a GPU parity test ------------------------------
+
+@pytest.mark.parametrize("rows", [4, 8, 16, 32, 64])
+def test_normals_lds_tile_sizes_byte_exact(topo, orc, rows):
+    """BASELINE config 3's knob: every instantiation of k_normals_interior<ROWS> (topo_set_normals_lds_rows) against the
+    oracle, on a 3x3 mosaic whose tile size is not a multiple of any ROWS (partial LDS tiles on both axes), both through
+    add_terrain (one tile per launch) and through topo_recompute_normals (the batched launch the bench times)."""
+    tile = 150
+    sc = Scene(tile, 3, 3)
+    g, o = both(topo, orc, 16, 16)
+    g.set_normals_lds_rows(rows)
+    sc.load(g)
+    sc.load(o)
+    ref = {loc: o.read_normals(loc[0], loc[1], tile, tile) for loc in sc.locs}
+    for loc in sc.locs:
+        a = g.read_normals(*loc)
+        assert np.array_equal(a, ref[loc]), f"rows {rows} add_terrain tile {loc}: {np.argwhere((a != ref[loc]).any(axis=-1))[:4]}"
+    g.recompute_normals()
+    for loc in sc.locs:
+        assert np.array_equal(g.read_normals(*loc), ref[loc]), f"rows {rows} recompute tile {loc}"
+    with pytest.raises(topo.TopoError):
+        g.set_normals_lds_rows(12)
+
+
+def test_config1_single_tile_small_panorama(topo, orc):
+    # BASELINE config 1 (the reference's CPU-plumbing case): one 1200x1200 tile, 1024x256 panorama = 8 sectors of 128x256
+    sc = Scene(1200, 1, 1, lat0=40, lon0=10, vfrac=(0.623, 0.717))
+    sw, sh = 128, 256
+    g, o = both(topo, orc, sw, sh)
+    sc.load(g)
+    sc.load(o)
+    for mode in (0, 1, 2):
+        views = sc.panorama(sw, sh, mode=mode)
+        rgba, depth = _strip(topo, g, views, sw, sh)
+        o.update(sw, sh, views[0], topo.post_uniforms(sw, sh))
+        ro, do = o.render_views(views, threads=8)
+        for k in range(8):
+            assert_same_frame((rgba[k], depth[k]), (ro[k], do[k]), f"config-1 mode {mode} sector {k}")
+    assert (depth < 1.0).mean() > 0.2
+
+
+def test_config3_mosaic25_sector_and_batching(topo, orc):
+    # BASELINE config 3: 5x5 degree mosaic (25 tiles of 1200x1200), 8192x2048 panorama = 8 sectors of 1024x2048
+    deg, sw, sh, tile = 5, 1024, 2048, 1200
+    sc = Scene(tile, deg, deg, lat0=40, lon0=10, vfrac=(0.5 + 0.123 / deg, 0.5 + 0.217 / deg))
+    g, o = both(topo, orc, sw, sh)
+    sc.load(g)
+    sc.load(o)
+    views = sc.panorama(sw, sh)
+    rgba, depth = _strip(topo, g, views, sw, sh)
+    # whole-panorama batching invariance: one submission = two halves = eight single-view submissions
+    for lo, hi in ((0, 4), (4, 8)) + tuple((k, k + 1) for k in (0, 3, 7)):
+        ra, da = _strip(topo, g, views[lo:hi], sw, sh)
+        assert np.array_equal(ra, rgba[lo:hi]) and np.array_equal(da.view(np.uint32), depth[lo:hi].view(np.uint32)), (lo, hi)
+    # one full-size sector against the oracle (seams between the 25 tiles are in view), + its normals
+    k = 5
+    o.update(sw, sh, views[k], topo.post_uniforms(sw, sh))
+    assert_same_frame((rgba[k], depth[k]), o.render(), f"config-3 sector {k}")
+    for loc in (sc.locs[0], sc.locs[12], sc.locs[24]):
+        assert np.array_equal(g.read_normals(*loc), o.read_normals(loc[0], loc[1], tile, tile))
+    assert (g.counters()["status"] & 2) == 0
+
+
+@pytest.fixture(scope="module")
+def mosaic100(topo, orc):
+    """The 10x10 degree COP90-shaped mosaic of BASELINE configs 4 and 5, resident once on the GPU and in the oracle."""
+    import math
+    deg, tile = 10, 1200
+    locs = topo.synth.mosaic_locations(40, 10, deg, deg)
+    g, o = topo.TerrainRenderer(512, 1024), orc.OracleRenderer(512, 1024)
+    heights = {}
+    for (la, lo) in locs:
+        h = topo.synth_tile(la, lo, tile, tile)
+        tr = topo.synth.tile_transform(la, lo, tile, tile)
+        g.add_terrain(la, lo, h, *tr)
+        o.add_terrain(la, lo, h, *tr)
+        heights[(la, lo)] = h
+    return {"g": g, "o": o, "locs": locs, "heights": heights, "deg": deg, "tile": tile}
+
+
+def test_config5_batch_submission_over_the_mosaic(topo, orc, mosaic100):
+    """BASELINE config 5's shape at full input size: 8 viewpoints x 8 sectors = 64 views of 512x1024 in ONE submission over
+    the 100-tile mosaic, two such submissions in flight (pipeline depth 2); three views of each against the oracle, and
+    the pipelined outputs against the serial ones."""
+    import math
+    import torch
+    g, o, sw, sh = mosaic100["g"], mosaic100["o"], 512, 1024
+    rng = np.random.default_rng(55)
+    sets = []
+    for s in range(2):
+        vs = []
+        for _ in range(8):
+            lat, lon, yaw = 41.0 + 8.0 * rng.random(), 11.0 + 8.0 * rng.random(), 2 * math.pi * rng.random()
+            key = (int(math.floor(lat)), int(math.floor(lon)))
+            ground = topo.synth.height_at(mosaic100["heights"][key], key[0], key[1], lon, lat)
+            eye = topo.geometry_transform(ground + 50.0, lon, lat)
+            vs += topo.panorama_uniforms(eye, yaw, sw, sh, lon, lat, 0)
+        sets.append(vs)
+    serial = [_strip(topo, g, vs, sw, sh) for vs in sets]
+    g.set_pipeline_depth(2)
+    outs = [(torch.zeros((64, sh, sw, 4), dtype=torch.uint8, device="cuda"), torch.zeros((64, sh, sw), dtype=torch.float32, device="cuda")) for _ in range(2)]
+    for rep in range(2):
+        for i, vs in enumerate(sets):
+            g.render_views_device(vs, sw, sh, outs[i][0].data_ptr(), sh * sw * 4, sw * 4, outs[i][1].data_ptr(), sh * sw * 4, sw * 4)
+    g.join()
+    g.set_pipeline_depth(1)
+    for i in range(2):
+        assert np.array_equal(outs[i][0].cpu().numpy(), serial[i][0]), f"pipelined submission {i}: colour"
+        assert np.array_equal(outs[i][1].cpu().numpy().view(np.uint32), serial[i][1].view(np.uint32)), f"pipelined submission {i}: depth"
+    assert g.frame_status()["status"] & 6 == 0
+    for i, pick in ((0, (0, 21, 63)), (1, (7, 40, 58))):
+        o.update(sw, sh, sets[i][pick[0]], topo.post_uniforms(sw, sh))
+        ro, do = o.render_views([sets[i][k] for k in pick], threads=3)
+        for j, k in enumerate(pick):
+            assert_same_frame((serial[i][0][k], serial[i][1][k]), (ro[j], do[j]), f"config-5 submission {i} view {k}")
+
+
+def test_visible_peaks_device_entry_point(topo, orc):
+    """topo_visible_peaks_device: peaks, depth and results stay in device memory (any view of a submission)."""
+    import torch
+    from scenes import random_peaks
+    sc = Scene(96, 2, 2, eye_dh=300.0)
+    sw, sh = 200, 120
+    g, o = both(topo, orc, sw, sh)
+    sc.load(g)
+    sc.load(o)
+    views = sc.panorama(sw, sh, yaw0_deg=33.0)
+    n = len(views)
+    rgba = torch.zeros((n, sh, sw, 4), dtype=torch.uint8, device="cuda")
+    pitch = topo.pad_256(4 * sw)                                    # the reference's depth row pitch
+    depth = torch.zeros((n, sh, pitch // 4), dtype=torch.float32, device="cuda")
+    g.set_stream(torch.cuda.current_stream().cuda_stream)
+    g.render_views_device(views, sw, sh, rgba.data_ptr(), sh * sw * 4, sw * 4, depth.data_ptr(), sh * pitch, pitch)
+    peaks = random_peaks(sc, 1500)
+    d_peaks = torch.from_numpy(peaks).cuda()
+    d_vis = torch.zeros(len(peaks), dtype=torch.uint8, device="cuda")
+    d_xy = torch.zeros((len(peaks), 2), dtype=torch.int32, device="cuda")
+    seen = 0
+    for k in (0, 3, 6):
+        g.visible_peaks_device(views[k], sw, sh, depth[k].data_ptr(), pitch, len(peaks), d_peaks.data_ptr(), d_vis.data_ptr(), d_xy.data_ptr())
+        torch.cuda.synchronize()
+        o.update(sw, sh, views[k], topo.post_uniforms(sw, sh))
+        o.render()
+        vo, xo = o.visible_peaks(peaks)
+        assert np.array_equal(d_vis.cpu().numpy().astype(bool), vo)
+        assert np.array_equal(d_xy.cpu().numpy().view(np.uint32), xo)
+        seen += int(vo.sum())
+    assert seen > 10
+
+
+def test_add_terrain_device_entry_point(topo, orc):
+    """topo_add_terrain_device (heights already in HBM) leaves the renderer in the state topo_add_terrain does."""
+    import torch
+    sc = Scene(80, 2, 2)
+    W, H = 160, 96
+    g, o = both(topo, orc, W, H)
+    keep = []
+    for loc in sc.locs:
+        d = torch.from_numpy(np.ascontiguousarray(sc.heights[loc])).cuda()
+        keep.append(d)
+        g.add_terrain_device(loc[0], loc[1], d.data_ptr(), 80, 80, *sc.transform(loc))
+        d.zero_()                                     # the call copied: the caller's buffer is free again
+    torch.cuda.synchronize()
+    sc.load(o)
+    for loc in sc.locs:
+        assert np.array_equal(g.read_normals(*loc), o.read_normals(loc[0], loc[1], 80, 80))
+    u, pu = sc.uniforms(W, H, 140, 15, 70, 0), topo.post_uniforms(W, H)
+    g.update(W, H, u, pu)
+    o.update(W, H, u, pu)
+    assert_same_frame(g.render(), o.render(), "after add_terrain_device")
+
+
+def test_bounds_checked_build_is_clean_and_identical(topo):
+    """libtopo_hip_check.so = the product with every device-side index tested before use (TOPO_BOUNDS_CHECK; the GPU
+    address sanitizer this pool does not offer).  The scenes of tests/bounds_scenes.py -- near-field giants, clipping, queue
+    overflows, a 64-view submission, odd sizes, a full-size config-2 panorama, frames in flight -- run through it in a
+    child process: no index may be out of range, and every frame must hash to what the product build renders."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import bounds_scenes
+    check = os.path.join(os.path.dirname(topo.LIB_PATH), "libtopo_hip_check.so")
+    assert os.path.exists(check), "run __graft_entry__.build()"
+    env = dict(os.environ, TOPO_HIP_LIB=check)
+    out = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "bounds_scenes.py")], env=env,
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    got = json.loads(out.stdout.strip().split("\n")[-1])
+    assert got["lib"].endswith("libtopo_hip_check.so")
+    want = bounds_scenes.run(topo)
+    assert set(got["cases"]) == set(want["cases"]) and len(want["cases"]) >= 12
+    for name, c in got["cases"].items():
+        assert not c["bounds_violation"], f"{name}: out-of-range index at site {c['bounds_site']}, value {c['bounds_value']}"
+        assert c["sha"] == want["cases"][name]["sha"], f"{name}: the checked build renders a different frame"
+        assert c["status"] == want["cases"][name]["status"]

@@ -1,0 +1,142 @@
+"""The oracle against an INDEPENDENT f64 ray caster (oracle/ray_check.py): depth and per-pixel winner, on scenes that
+would expose a misread handedness, yaw/pitch sign, grid orientation, winding, depth range or field of view -- the class of
+error a same-author restatement shares between oracle and product and that bit-exact parity cannot see.
+Also: known-answer identities of the glam 0.31 functions the camera path restates (documented properties of the crate)."""
+import math
+
+import numpy as np
+import pytest
+
+from oracle import ray_check as RC
+from scenes import Scene
+
+def relief(lat, lon):
+    """Strong, asymmetric relief at the scale of a coarse test tile (the fBm of the benchmark tiles is almost flat over
+    a 24-texel degree): kilometre-high ridges a tenth of a degree apart, no symmetry between the axes."""
+    return 1500.0 + 900.0 * np.sin(np.radians(37.0 * lon + 11.0 * lat)) * np.cos(np.radians(53.0 * lat)) \
+        + 500.0 * np.sin(np.radians(140.0 * lon)) + 0.0 * lat
+
+
+SCENES = [
+    # tile, n_lat, n_lon, lat0, lon0, W, H, yaw, pitch, fov, eye_dh
+    # (coarse tiles: vertices kilometres apart, so the eye sits kilometres up to be above the mesh it looks at)
+    (24, 2, 2, 45, 15, 96, 64, 30.0, 25.0, 60.0, 4000.0),      # north-east quadrant, four tiles, the gaps between them in view
+    (32, 1, 1, 45, 15, 80, 80, 250.0, 60.0, 90.0, 6000.0),     # steeply down: triangles tens of px across
+    (16, 3, 3, -34, -71, 96, 48, 200.0, 30.0, 79.28, 8000.0),  # southern + western hemisphere, panorama sector FOV
+]
+
+
+@pytest.mark.parametrize("cfg", SCENES, ids=["ne_2x2", "down_1x1", "sw_3x3"])
+def test_oracle_agrees_with_f64_ray_cast(orc, cfg):
+    tile, n_lat, n_lon, lat0, lon0, W, H, yaw, pitch, fov, dh = cfg
+    sc = Scene(tile, n_lat, n_lon, lat0=lat0, lon0=lon0, eye_dh=dh, height_fn=relief)
+    o = orc.OracleRenderer(W, H)
+    sc.load(o)
+    # the Uniforms block is made by the PRODUCT's host code (topo_camera_uniforms: the glam restatement); the ray caster
+    # gets only (eye, yaw, pitch, fov) and derives its own camera
+    o.update(W, H, sc.uniforms(W, H, yaw, pitch, fov, 1), np.array([W, H, 100.0, 0.0], np.float32))
+    od, ow = o.render_winners()
+    import topo_renderer_amd as T
+    order = sorted(sc.locs, key=lambda l: (abs(l[0]), 1 if l[0] > 0 else 0, abs(l[1]), 1 if l[1] > 0 else 0))    # BTreeMap<GeoLocation> order
+    tiles = [(sc.heights[l],) + tuple(T.synth.tile_transform(l[0], l[1], tile, tile)) for l in order]
+    rd, rw, mb, any_t = RC.ray_cast(tiles, sc.eye, math.radians(yaw), math.radians(pitch), math.radians(fov), W, H)
+    st = RC.compare(od, ow, rd, rw, mb)
+    assert st["terrain_pixels_ray"] > 0.25 * W * H and st["interior_pixels"] > 0.15 * W * H, st
+    assert st["interior_winner_agree"] >= 0.999, st          # the oracle's owner is the nearest front-facing triangle
+    assert st["interior_depth_within_tol"] >= 0.999, st      # ... at the ray's depth (4 clip units / view depth + 4 ulp: see compare())
+    assert st["sky_agree"] >= 0.99, st                        # silhouettes may move by the sub-pixel snapping only
+    assert st["all_winner_agree"] >= 0.97, st
+    # from above the surface nothing inside-out is in front: the nearest hit overall is the nearest front-facing hit
+    front_t = RC.FAR * RC.NEAR / (RC.FAR - rd * (RC.FAR - RC.NEAR))
+    hit = rw >= 0
+    assert (np.abs(any_t[hit] - front_t[hit]) <= 1e-6 * front_t[hit]).mean() > 0.995
+
+
+def test_ray_cast_detects_misreadings(orc):
+    """The checker has teeth: the oracle fed a mirrored yaw, a negated pitch or a transposed height grid no longer agrees."""
+    import topo_renderer_amd as T
+    tile, W, H, yaw, pitch, fov = 24, 64, 48, 30.0, 25.0, 60.0
+    sc = Scene(tile, 2, 2, eye_dh=4000.0, height_fn=relief)
+    order = sorted(sc.locs, key=lambda l: (abs(l[0]), 1 if l[0] > 0 else 0, abs(l[1]), 1 if l[1] > 0 else 0))
+    tiles = [(sc.heights[l],) + tuple(T.synth.tile_transform(l[0], l[1], tile, tile)) for l in order]
+    rd, rw, mb, _ = RC.ray_cast(tiles, sc.eye, math.radians(yaw), math.radians(pitch), math.radians(fov), W, H)
+    pu = np.array([W, H, 100.0, 0.0], np.float32)
+
+    def agree(uniforms, transpose=False):
+        o = orc.OracleRenderer(W, H)
+        for l in sc.locs:
+            h = sc.heights[l].T.copy() if transpose else sc.heights[l]
+            o.add_terrain(l[0], l[1], h, *sc.transform(l))
+        o.update(W, H, uniforms, pu)
+        od, ow = o.render_winners()
+        return RC.compare(od, ow, rd, rw, mb)["interior_winner_agree"]
+
+    assert agree(sc.uniforms(W, H, yaw, pitch, fov, 1)) >= 0.999
+    assert agree(sc.uniforms(W, H, -yaw, pitch, fov, 1)) < 0.5
+    assert agree(sc.uniforms(W, H, yaw, -pitch, fov, 1)) < 0.5
+    assert agree(sc.uniforms(W, H, yaw, pitch, fov * 1.2, 1)) < 0.5
+    assert agree(sc.uniforms(W, H, yaw, pitch, fov, 1), transpose=True) < 0.95     # (the acceptance threshold is 0.999)
+
+
+# ---- glam 0.31 identities (documented properties of the crate's functions; the reference's call sites: camera.rs:102-128) ----
+
+def _mat(u, off=0):
+    return np.asarray(u[off:off + 16], np.float64).reshape(4, 4).T      # column-major -> [row, col]
+
+
+def test_glam_identities_of_the_camera_block():
+    import topo_renderer_amd as T
+    rng = np.random.default_rng(4)
+    for _ in range(50):
+        lat, lon = rng.uniform(-80, 80), rng.uniform(-179, 179)
+        eye32 = T.geometry_transform(float(rng.uniform(0, 4000)), float(lon), float(lat))
+        eye = eye32.astype(np.float64)
+        yaw, pitch, fov = rng.uniform(-math.pi, math.pi), rng.uniform(-1.2, 1.2), rng.uniform(0.3, 2.4)
+        W, H = 640.0, 360.0
+        u = T.camera_uniforms(eye32, float(yaw), float(pitch), float(fov), W, H, float(lon), float(lat), 0)
+        M = _mat(u)
+        f, s, up_cam = RC.camera_basis(eye, yaw, pitch)
+        tol = 2e-5
+
+        def ndc(p):
+            c = M @ np.append(p, 1.0)
+            return c[:3] / c[3], c[3]
+        # perspective_rh (depth 0..1): a point on the view axis at distance near maps to z = 0, at far to z = 1, to the screen centre
+        for d, z in ((RC.NEAR, 0.0), (RC.FAR, 1.0), (1000.0, RC.FAR * (1000.0 - RC.NEAR) / ((RC.FAR - RC.NEAR) * 1000.0))):
+            n, w = ndc(eye + d * f)
+            assert abs(n[0]) < 2e-3 and abs(n[1]) < 2e-3 and abs(n[2] - z) < 5e-4 and abs(w - d) < 1e-3 * d + 1.0, (d, n, w)
+        # right-handed: +x of the screen is `right` = f x up, +y is the camera's up; the field of view is vertical
+        d = 5000.0
+        th = math.tan(0.5 * fov)
+        n, _ = ndc(eye + d * (f + 0.5 * th * up_cam))
+        assert abs(n[1] - 0.5) < 5e-3 and abs(n[0]) < 5e-3
+        n, _ = ndc(eye + d * (f + 0.5 * th * (W / H) * s))
+        assert abs(n[0] - 0.5) < 5e-3 and abs(n[1]) < 5e-3
+        # Quat::from_rotation_arc(a, b) * a == b: with yaw = pitch = 0 the local vector (1,0,0) is orthogonal to -Y, and the
+        # arc is the MINIMAL rotation: it maps -Y to up and keeps the axis (-Y x up) fixed
+        R = RC.rotation_arc([0, -1, 0], eye / np.linalg.norm(eye))
+        assert np.allclose(R @ np.array([0, -1.0, 0]), eye / np.linalg.norm(eye), atol=1e-12)
+        ax = np.cross([0, -1.0, 0], eye / np.linalg.norm(eye))
+        assert np.allclose(R @ ax, ax, atol=1e-12) and abs(np.linalg.det(R) - 1) < 1e-12
+        # pitch > 0 looks DOWN (towards the planet centre) -- the reference's convention (local y axis = -up)
+        f_down, _, _ = RC.camera_basis(eye, yaw, 0.5)
+        assert np.dot(f_down, eye) < np.dot(f, eye) if pitch < 0.5 else True
+        # sun_direction = LightAngle{theta: lon, phi: lat}.to_vec3() = the zenith of (lat, lon): geometry::transform's direction
+        sun = np.asarray(u[36:39], np.float64)
+        assert np.allclose(sun, eye / np.linalg.norm(eye), atol=2e-3)       # (eye = geometry::transform at the same lon/lat)
+        assert abs(np.linalg.norm(sun) - 1.0) < tol
+
+
+def test_terrain_rotation_is_the_local_frame():
+    """Mat3::from_euler(XYZEx, 0, rad(90 - lat), rad(lon)) (render/data.rs:125-133) = Rz(lon) * Ry(90 - lat): it must take the
+    tile-local 'up' (0,0,1) of the normal stencil to the zenith of (lat, lon) and local east to geographic east."""
+    import topo_renderer_amd as T
+    for lat, lon in ((45.0, 15.0), (-34.0, -71.0), (0.0, 0.0), (60.0, 170.0)):
+        tu = T.terrain_uniforms((0, 0), (lon, lat), (1 / 1200, 1 / 1200), 1200, 1200)
+        R = np.asarray(tu[8:24], np.float64).reshape(4, 4).T[:3, :3]
+        zen = np.array([math.cos(math.radians(lat)) * math.cos(math.radians(lon)), math.cos(math.radians(lat)) * math.sin(math.radians(lon)),
+                        math.sin(math.radians(lat))])
+        assert np.allclose(R @ np.array([0, 0, 1.0]), zen, atol=1e-6)
+        assert np.allclose(R.T @ R, np.eye(3), atol=1e-6) and abs(np.linalg.det(R) - 1) < 1e-6
+        east = np.array([-math.sin(math.radians(lon)), math.cos(math.radians(lon)), 0.0])
+        assert np.allclose(R @ np.array([0, 1.0, 0]), east, atol=1e-6)

@@ -43,7 +43,7 @@ class TopoError(RuntimeError):
 
 def build(verbose: bool = False) -> str:
     """Compile libtopo_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
-    subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc")] + ([] if verbose else ["-s"]))
+    subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), "all"] + ([] if verbose else ["-s"]))
     return LIB_PATH
 
 
@@ -99,6 +99,7 @@ def lib():
             "topo_probe_div": (C.c_int, [vp, i32, vp, vp, vp, sz]),
             "topo_set_pipeline_depth": (C.c_int, [vp, i32]),
             "topo_join": (C.c_int, [vp]),
+            "topo_frame_status": (C.c_int, [vp, vp]),
             "topo_visible_peaks": (C.c_int, [vp, u32, vp, vp, vp]),
             "topo_visible_peaks_device": (C.c_int, [vp, vp, u32, u32, vp, sz, u32, vp, vp, vp]),
             "topo_camera_uniforms": (None, [vp, f32, f32, f32, f32, f32, f32, f32, i32, vp]),
@@ -360,6 +361,13 @@ class TerrainRenderer:
 
     def synchronize(self):
         self._check(lib().topo_synchronize(self._h))
+
+    def frame_status(self) -> dict:
+        """Status of the last frame waited for (topo_frame_status): bits + the bounds record of the check build."""
+        out = np.zeros(4, np.uint32)
+        self._check(lib().topo_frame_status(self._h, _p(out)))
+        return {"status": int(out[0]), "big_overflow": bool(out[0] & 1), "rare_overflow": bool(out[0] & 2), "bounds_violation": bool(out[0] & 4),
+                "bounds_site": int(out[1]), "bounds_value": int(out[2]) | (int(out[3]) << 32)}
 
     def set_normals_lds_rows(self, rows: int):
         self._check(lib().topo_set_normals_lds_rows(self._h, rows))

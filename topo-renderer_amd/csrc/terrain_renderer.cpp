@@ -86,6 +86,7 @@ TerrainRenderer::~TerrainRenderer() {
             if (e) (void)hipEventDestroy(e);
         if (c.done) (void)hipEventDestroy(c.done);
         if (c.stream) (void)hipStreamDestroy(c.stream);
+        if (c.h_status) (void)hipHostFree(c.h_status);
     }
     for (auto& e : load_ev_)
         if (e) (void)hipEventDestroy(e);
@@ -313,6 +314,29 @@ int TerrainRenderer::join() {
     return TOPO_OK;
 }
 
+// The status word of a frame is per frame (k_clear resets it, render_frame copies the counters to pinned memory behind
+// k_resolve).  Called once the frames' streams have been waited for: a frame whose rare-triangle queue overflowed has
+// dropped triangles -- its outputs are incomplete -- and that is an error of the call that waited for it
+// (topo_join / topo_synchronize / topo_render / topo_get_counters), reported once per frame.
+bool TerrainRenderer::fold_frames(FrameCtx& c) {
+    bool overflow = false;
+    for (; c.checked < c.submitted; ++c.checked) {
+        const uint32_t* w = c.h_status + (c.checked % kStatusRing) * 16;
+        last_status_[0] = w[2]; last_status_[1] = w[8]; last_status_[2] = w[9]; last_status_[3] = w[10];
+        overflow |= (w[2] & kStatusRareOverflow) != 0;
+    }
+    return overflow;
+}
+
+int TerrainRenderer::check_frames() {
+    bool overflow = overflow_pending_;
+    overflow_pending_ = false;
+    for (auto& c : ctx_)
+        if (!c.pending && c.h_status) overflow |= fold_frames(c);
+    if (overflow) return fail(TOPO_ERR_CAPACITY, "rare-triangle queue overflowed: a frame is incomplete (raise the queue capacity or render fewer views per submission)");
+    return TOPO_OK;
+}
+
 int TerrainRenderer::set_pipeline_depth(int depth) {
     if (depth < 1 || depth > kMaxPipeline) return fail(TOPO_ERR_INVALID, "pipeline depth must be 1..4");
     if (int rc = join()) return rc;
@@ -349,7 +373,8 @@ int TerrainRenderer::render_frame(FrameCtx& c, hipStream_t stream, uint32_t n, c
     const uint32_t bxc = n_tiles ? (tile_w_ - 1 + kBCX - 1) / kBCX : 0, byc = n_tiles ? (tile_h_ - 1 + kBCY - 1) / kBCY : 0;
     const size_t pixels = (size_t)n * w * h;
     const size_t work_cap = (size_t)n * n_tiles * bxc * byc;
-    const size_t big_cap = big_cap_cfg_ ? big_cap_cfg_ : (1u << 22), rare_cap = rare_cap_cfg_ ? rare_cap_cfg_ : (1u << 22);
+    const size_t big_cap = big_cap_cfg_ ? big_cap_cfg_ : (1u << 22);
+    const size_t rare_cap = rare_cap_cfg_ ? rare_cap_cfg_ : (rare_cap_auto_ ? (size_t)rare_cap_auto_ : (1u << 22));
     if (work_cap >= (1ull << 30)) return fail(TOPO_ERR_CAPACITY, "too many raster blocks in one submission");
     if (pixels >= (1ull << 32)) return fail(TOPO_ERR_CAPACITY, "more than 2^32 pixels in one submission");
     const size_t vis_keys = (pixels + 63) & ~(size_t)63;   // whole 64-key segments: k_clear rewrites segments, not keys
@@ -369,6 +394,11 @@ int TerrainRenderer::render_frame(FrameCtx& c, hipStream_t stream, uint32_t n, c
     if (!c.d_counters) {
         if (int rc = ensure_on(stream, &c.d_counters, &c.cap_counters, 16 * sizeof(uint32_t))) return rc;
         TOPO_HIP_TRY(hipMemsetAsync(c.d_counters, 0, 16 * sizeof(uint32_t), stream));
+    }
+    if (!c.h_status) TOPO_HIP_TRY(hipHostMalloc((void**)&c.h_status, kStatusRing * 16 * sizeof(uint32_t)));
+    if (c.submitted - c.checked == kStatusRing) {      // nobody has waited for this context's frames for a whole ring: fold them now
+        TOPO_HIP_TRY(hipStreamSynchronize(stream));
+        overflow_pending_ |= fold_frames(c);
     }
     // view constants go through a small ring of pinned staging slots, each guarded by an event, so a submission
     // never has to wait for the stream (pageable sources would force a synchronous staging copy)
@@ -468,6 +498,9 @@ int TerrainRenderer::render_frame(FrameCtx& c, hipStream_t stream, uint32_t n, c
     if (ev_need & (1u << 7)) TOPO_HIP_TRY(hipEventRecord(c.ev[7], stream));
     launch_resolve(p, out, stream);
     if (ev_need & (1u << 8)) TOPO_HIP_TRY(hipEventRecord(c.ev[8], stream));
+    // this frame's counters (queue fills, status bits), for whoever waits for the frame (check_frames, get_counters)
+    TOPO_HIP_TRY(hipMemcpyAsync(c.h_status + (c.submitted % kStatusRing) * 16, c.d_counters, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    ++c.submitted;
     c.timed = true;
     TOPO_HIP_TRY(hipGetLastError());
     return TOPO_OK;
@@ -504,15 +537,29 @@ int TerrainRenderer::render(uint8_t* rgba, size_t rgba_pitch, float* depth, size
     o.depth = depth ? (float*)d_out_depth_ : nullptr;
     o.depth_view_stride = row * H_;
     o.depth_pitch = row;
-    if (int rc = render_views_device(1, &uniforms_, W_, H_, o)) return rc;
-    if (int rc = join()) return rc;       // (pipelined contexts run on their own streams)
-    void* d_counters_ = ctx_[last_ctx_].d_counters;
+    // A frame whose rare-triangle queue overflowed is incomplete.  The synchronous entry point does not hand such a frame
+    // out: it grows the queue to what the frame asked for and renders it again (an explicit topo_debug_set_queue_caps
+    // setting is a test hook and is left alone: then the call fails with TOPO_ERR_CAPACITY).
+    if (int rc = synchronize()) return rc;     // frames queued earlier through the asynchronous entry points report here
+    for (int attempt = 0;; ++attempt) {
+        if (int rc = render_views_device(1, &uniforms_, W_, H_, o)) return rc;
+        if (int rc = join()) return rc;       // (pipelined contexts run on their own streams)
+        TOPO_HIP_TRY(hipStreamSynchronize(stream_));
+        FrameCtx& fc = ctx_[last_ctx_];
+        const uint32_t* words = fc.h_status + ((fc.submitted - 1) % kStatusRing) * 16;
+        const uint32_t status = words[2], wanted = words[3];
+        if (!(status & kStatusRareOverflow) || rare_cap_cfg_ != 0 || attempt >= 3) {
+            (void)check_frames();          // (folds this frame's words; its status is answered for right here)
+            if (status & kStatusRareOverflow) return fail(TOPO_ERR_CAPACITY, "rare-triangle queue overflowed: frame incomplete");
+            break;
+        }
+        (void)check_frames();
+        rare_cap_auto_ = (uint64_t)wanted + wanted / 4u + 1024u;      // the overflowed frame counted what it needs
+        if (rare_cap_auto_ > (1ull << 28)) return fail(TOPO_ERR_CAPACITY, "rare-triangle queue would exceed 2^28 entries");
+    }
     TOPO_HIP_TRY(hipMemcpy2DAsync(rgba, rgba_pitch, d_out_rgba_, row, row, H_, hipMemcpyDeviceToHost, stream_));
     if (depth) TOPO_HIP_TRY(hipMemcpy2DAsync(depth, depth_pitch, d_out_depth_, row, row, H_, hipMemcpyDeviceToHost, stream_));
     TOPO_HIP_TRY(hipStreamSynchronize(stream_));
-    uint32_t status = 0;
-    TOPO_HIP_TRY(hipMemcpy(&status, (uint32_t*)d_counters_ + 2, sizeof status, hipMemcpyDeviceToHost));
-    if (status & kStatusRareOverflow) return fail(TOPO_ERR_CAPACITY, "rare-triangle queue overflowed: frame incomplete");
     have_depth_ = depth != nullptr;
     depth_w_ = W_;
     depth_h_ = H_;
@@ -560,6 +607,20 @@ int TerrainRenderer::set_stream(hipStream_t s) {
 int TerrainRenderer::synchronize() {
     if (int rc = join()) return rc;
     TOPO_HIP_TRY(hipStreamSynchronize(stream_));
+    return check_frames();
+}
+
+int TerrainRenderer::join_frames() {
+    if (int rc = join()) return rc;
+    if (pipeline_depth_ == 1) TOPO_HIP_TRY(hipStreamSynchronize(stream_));      // one frame in flight: it runs on stream_
+    return check_frames();
+}
+
+int TerrainRenderer::frame_status(uint32_t out[4]) {
+    if (int rc = join()) return rc;
+    TOPO_HIP_TRY(hipStreamSynchronize(stream_));
+    (void)check_frames();       // refreshes last_status_; an overflow is reported through out[0], not as an error of this call
+    for (int i = 0; i < 4; ++i) out[i] = last_status_[i];
     return TOPO_OK;
 }
 
@@ -582,12 +643,10 @@ int TerrainRenderer::set_occlusion_split(float metres) {
 
 int TerrainRenderer::set_queue_caps(uint32_t big_cap, uint32_t rare_cap) {
     big_cap_cfg_ = big_cap;
-    rare_cap_cfg_ = rare_cap;
-    if (int rc = join()) return rc;
-    for (auto& c : ctx_)
-        if (c.d_counters)   // the status bits are sticky across frames: a new configuration starts clean
-            TOPO_HIP_TRY(hipMemsetAsync(c.d_counters, 0, 16 * sizeof(uint32_t), pipeline_depth_ > 1 && c.stream ? c.stream : stream_));
-    return TOPO_OK;
+    // bit 31 of rare_cap: "start at this capacity but grow on demand" (what the default does from 4 Mi entries)
+    rare_cap_cfg_ = (rare_cap & 0x80000000u) ? 0u : rare_cap;
+    rare_cap_auto_ = (rare_cap & 0x80000000u) ? (rare_cap & 0x7FFFFFFFu) : 0u;
+    return join();
 }
 
 int TerrainRenderer::get_timings(float out[TOPO_TIMING_SLOTS]) {
@@ -624,12 +683,11 @@ int TerrainRenderer::get_timings(float out[TOPO_TIMING_SLOTS]) {
 int TerrainRenderer::get_counters(uint32_t out[6]) {
     for (int i = 0; i < 6; ++i) out[i] = 0;
     FrameCtx& fc = ctx_[last_ctx_];
-    void* d_counters_ = fc.d_counters;
-    if (!d_counters_) return TOPO_OK;
+    if (!fc.h_status) return TOPO_OK;
     if (int rc = bind_device()) return rc;
     TOPO_HIP_TRY(hipStreamSynchronize(pipeline_depth_ > 1 ? fc.stream : stream_));
-    uint32_t c[16];
-    TOPO_HIP_TRY(hipMemcpy(c, d_counters_, sizeof c, hipMemcpyDeviceToHost));
+    uint32_t c[16] = {};
+    if (fc.submitted) memcpy(c, fc.h_status + ((fc.submitted - 1) % kStatusRing) * 16, sizeof c);
     if (getenv("TOPO_DEBUG_COUNTERS")) {   // raw queue counters, for kernel experiments
         fprintf(stderr, "[topo] counters:");
         for (int i = 0; i < 16; ++i) fprintf(stderr, " %u", c[i]);

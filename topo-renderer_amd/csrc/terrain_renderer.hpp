@@ -51,11 +51,13 @@ class TerrainRenderer {
     int set_stream(hipStream_t s);
     int synchronize();
     int set_pipeline_depth(int depth);
-    int join();
+    int join();                 // waits for the frames in flight on the contexts' own streams
+    int join_frames();          // topo_join: join + the frames' status (TOPO_ERR_CAPACITY for an incomplete frame)
     int set_normals_lds_rows(int rows);
     int set_queue_caps(uint32_t big_cap, uint32_t rare_cap);
     int get_timings(float out[TOPO_TIMING_SLOTS]);
     int get_counters(uint32_t out[6]);
+    int frame_status(uint32_t out[4]);
     int set_occlusion_split(float metres);
     int set_timing_slots(uint32_t mask);
     int read_normals(int32_t lat, int32_t lon, uint8_t* out);
@@ -94,6 +96,7 @@ class TerrainRenderer {
     bool table_dirty_ = true;
     int lds_rows_ = 16;
     uint32_t big_cap_cfg_ = 0, rare_cap_cfg_ = 0;
+    uint64_t rare_cap_auto_ = 0;           // rare-queue capacity topo_render grew to after an overflow (0 = default)
     uint32_t timing_slots_ = 0x3Fu;        // topo_set_timing_slots: which per-kernel durations to measure
     float occlusion_split_m_ = 90000.0f;   // flat optimum 60..120 km at c4 (profiles/README.md)
 
@@ -110,6 +113,10 @@ class TerrainRenderer {
         hipEvent_t ev[kNumEvents] = {};
         hipEvent_t done = nullptr;
         bool timed = false, pending = false;
+        // pinned ring of the last kStatusRing frames' 16 counter words, each copied out in stream order behind its k_resolve;
+        // frames [checked, submitted) have not been looked at by check_frames yet
+        uint32_t* h_status = nullptr;
+        uint64_t submitted = 0, checked = 0;
         uint32_t ev_recorded = 0, slots = 0;  // which of ev[] the last frame recorded, for which timing slots
         void* d_vis = nullptr;      size_t cap_vis = 0;
         void* d_dirty = nullptr;    size_t cap_dirty = 0;   // one mark per 64 visibility keys (topo_kernels.hip: struct Vis)
@@ -121,9 +128,14 @@ class TerrainRenderer {
         void* d_counters = nullptr; size_t cap_counters = 0;
     };
     static constexpr int kMaxPipeline = 4;
+    static constexpr uint64_t kStatusRing = 64;
     FrameCtx ctx_[kMaxPipeline];
     int pipeline_depth_ = 1, next_ctx_ = 0, last_ctx_ = 0;
     int init_ctx(FrameCtx& c, bool own_stream);
+    int check_frames();                        // after a wait: turn a finished frame's overflow status into TOPO_ERR_CAPACITY
+    uint32_t last_status_[4] = {};             // status word + bounds record of the last frame looked at
+    bool fold_frames(FrameCtx& c);             // folds the finished, unchecked frames of c into last_status_; true if one overflowed
+    bool overflow_pending_ = false;
     int ensure_on(hipStream_t s, void** p, size_t* cap, size_t need);
     int render_frame(FrameCtx& c, hipStream_t s, uint32_t n, const topo_uniforms* views, uint32_t w, uint32_t h, const OutputParams& out);
 

@@ -173,7 +173,13 @@ int topo_set_pipeline_depth(topo_ctx* ctx, int32_t depth) {
 
 int topo_join(topo_ctx* ctx) {
     TOPO_GUARD(ctx);
-    TOPO_CALL(ctx->r->join());
+    TOPO_CALL(ctx->r->join_frames());
+}
+
+int topo_frame_status(topo_ctx* ctx, uint32_t out[4]) {
+    TOPO_GUARD(ctx);
+    if (!out) return TOPO_ERR_INVALID;
+    TOPO_CALL(ctx->r->frame_status(out));
 }
 
 int topo_probe_div(topo_ctx* ctx, int32_t kind, const float* x, const float* y, float* out, size_t n) {

@@ -45,7 +45,8 @@ struct FrameParams {
     uint8_t* dirty;            // one byte per 64 consecutive keys: 1 = some key of the segment was written this frame
     WorkItem* work;
     uint32_t* counters;        // [0] near work count, [1] big count, [2] status bits, [3] rare count, [4] far candidates,
-                               // [5] far survivors, [6] big start, [7] rare start (of the current phase)
+                               // [5] far survivors, [6] big start, [7] rare start (of the current phase), [8..10] first
+                               // bounds violation (check build); 16 words, all reset by k_clear at the start of a frame
     BigItem* big;
     RareItem* rare;
     FarItem* far;              // far candidates (k_cull -> k_occlusion)
@@ -71,6 +72,8 @@ struct OutputParams {
 
 constexpr uint32_t kStatusBigOverflow = 1u;    // big-triangle queue full: handled in-lane (slower, still exact)
 constexpr uint32_t kStatusRareOverflow = 2u;   // rare-triangle queue full: triangles were DROPPED -> the frame is invalid
+constexpr uint32_t kStatusBounds = 4u;         // TOPO_BOUNDS_CHECK build only: an out-of-range index was formed (and not used);
+                                               // counters[8] = site tag, counters[9..10] = the offending value
 
 // load phase (add_terrain).  Every pass of the reference's add_terrain writes a disjoint set of texels (interior
 // / one seam per adjacent pair / one corner per 2x2 block), so any number of them can run in one launch each;

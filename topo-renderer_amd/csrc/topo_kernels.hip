@@ -14,6 +14,8 @@
 // Compiled with -ffp-contract=off: results must match the arithmetic spec bit for bit.
 #include "topo_kernels.h"
 
+#include <atomic>
+
 namespace topo {
 
 namespace {
@@ -29,11 +31,42 @@ struct Vis {
     uint64_t* p;             // this view's keys
     const uint64_t* base;    // the whole buffer (segment numbers are global)
     uint8_t* dirty;
+#ifdef TOPO_BOUNDS_CHECK
+    uint32_t* counters;
+    size_t view_keys;        // W * H
+#endif
 };
+
+// TOPO_BOUNDS_CHECK build (libtopo_hip_check.so, `make check`): every index this file forms into the visibility buffer,
+// the segment marks, the queues, the tile rasters and the outputs is tested first; a violation sets kStatusBounds,
+// records (site tag, offending value) of the first one in counters[8..10] and the access is skipped instead of made.
+// It is the address sanitizer this pool does not offer for the GPU (tests/test_gpu_parity.py runs the suite's scenes
+// through it once).  In the product build TOPO_CHK is `true` and costs nothing.
+#ifdef TOPO_BOUNDS_CHECK
+__device__ __noinline__ void bounds_violation(uint32_t* counters, uint32_t tag, uint64_t value) {
+    if ((atomicOr(&counters[2], kStatusBounds) & kStatusBounds) == 0) {
+        counters[8] = tag;
+        counters[9] = (uint32_t)value;
+        counters[10] = (uint32_t)(value >> 32);
+    }
+}
+#define TOPO_CHK(counters, ok, tag, value) ((ok) ? true : (bounds_violation((counters), (tag), (uint64_t)(value)), false))
+#else
+#define TOPO_CHK(counters, ok, tag, value) true
+#endif
+
 __device__ __forceinline__ Vis view_vis(const FrameParams& P, uint32_t view) {
+#ifdef TOPO_BOUNDS_CHECK
+    (void)TOPO_CHK(P.counters, view < P.n_views, 1u, view);
+    return Vis{P.vis + (size_t)view * P.W * P.H, P.vis, P.dirty, P.counters, (size_t)P.W * P.H};
+#else
     return Vis{P.vis + (size_t)view * P.W * P.H, P.vis, P.dirty};
+#endif
 }
 __device__ __forceinline__ void vis_min(const Vis& v, size_t pix, uint64_t key) {
+#ifdef TOPO_BOUNDS_CHECK
+    if (!TOPO_CHK(v.counters, pix < v.view_keys, 2u, pix)) return;
+#endif
     uint64_t* q = v.p + pix;
     atomicMin(reinterpret_cast<unsigned long long*>(q), (unsigned long long)key);
     v.dirty[(size_t)(q - v.base) >> 6] = 1;
@@ -219,7 +252,7 @@ __global__ __launch_bounds__(64) void k_normals_corner(const TileDev* __restrict
 // A wave takes 64 segments at a time: one coalesced read of their marks, then one 512-byte store per marked segment.
 __global__ __launch_bounds__(256) void k_clear(uint64_t* __restrict__ vis, uint8_t* __restrict__ dirty, size_t n,
                                                uint32_t* __restrict__ counters) {
-    if (blockIdx.x == 0 && threadIdx.x < 8 && threadIdx.x != 2) counters[threadIdx.x] = 0;   // all queue counters (status is sticky)
+    if (blockIdx.x == 0 && threadIdx.x < 12) counters[threadIdx.x] = 0;   // queue counters and this frame's status word
     const uint32_t lane = threadIdx.x & 63;
     const size_t nseg = (n + 63) >> 6, wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwave = (size_t)gridDim.x * 4;
     for (size_t g = wave * 64; g < nseg; g += nwave * 64) {
@@ -229,7 +262,8 @@ __global__ __launch_bounds__(256) void k_clear(uint64_t* __restrict__ vis, uint8
         while (todo) {
             const size_t seg = g + (size_t)__builtin_ctzll(todo);
             todo &= todo - 1;
-            vis[seg * 64 + lane] = kVisClear;      // the buffer is allocated in whole segments
+            if (TOPO_CHK(counters, seg * 64 + lane < ((n + 63) & ~(size_t)63), 3u, seg * 64 + lane))
+                vis[seg * 64 + lane] = kVisClear;      // the buffer is allocated in whole segments
         }
     }
 }
@@ -278,7 +312,7 @@ __device__ __forceinline__ void emit_near(const FrameParams& P, uint32_t view, u
         const uint32_t n = (cell_rows + kStrip - 1) / kStrip;
         const uint32_t base = atomicAdd(&P.counters[0], n);
         for (uint32_t k = 0; k < n; ++k)
-            if (base + k < P.near_cap)
+            if (base + k < P.near_cap && TOPO_CHK(P.counters, blk < (1u << 24) && kStrip * k < 16u, 4u, blk))
                 P.work[base + k] = WorkItem{(view << 16) | rank, blk | ((kStrip * k) << 24) | (min(kStrip, cell_rows - kStrip * k) << 28)};
         return;
     }
@@ -324,7 +358,10 @@ __global__ __launch_bounds__(256) void k_cull(FrameParams P) {
             // view depth of the nearest point the block can contain
             const double wn = sqrt((double)m[3] * m[3] + (double)m[7] * m[7] + (double)m[11] * m[11]);
             const double w_near = ((double)m[3] * c[0] + (double)m[7] * c[1] + (double)m[11] * c[2] + (double)m[15]) - radius * wn;
-            if (sane && P.split_m > 0.0f && w_near > (double)P.split_m) s_far[atomicAdd(&s_nfar, 1u)] = threadIdx.x;
+            if (sane && P.split_m > 0.0f && w_near > (double)P.split_m) {
+                const uint32_t fslot = atomicAdd(&s_nfar, 1u);
+                if (TOPO_CHK(P.counters, fslot < 256u, 5u, fslot)) s_far[fslot] = threadIdx.x;
+            }
             else emit_near(P, view, rank, blk);
         }
     }
@@ -405,7 +442,10 @@ __global__ __launch_bounds__(256) void k_occlusion(FrameParams P) {
             for (uint32_t y = fi.y0; y <= fi.y1; y += 4) {
                 uint32_t d[4];
 #pragma unroll
-                for (uint32_t k = 0; k < 4; ++k) d[k] = (uint32_t)(vis[(size_t)min(y + k, (uint32_t)fi.y1) * P.W + px] >> 32);
+                for (uint32_t k = 0; k < 4; ++k) {
+                    const size_t at = (size_t)min(y + k, (uint32_t)fi.y1) * P.W + px;
+                    d[k] = TOPO_CHK(P.counters, at < (size_t)P.W * P.H && (fi.view_rank >> 16) < P.n_views, 6u, at) ? (uint32_t)(vis[at] >> 32) : 0u;
+                }
                 const bool open = d[0] >= fi.zmin_bits || d[1] >= fi.zmin_bits || d[2] >= fi.zmin_bits || d[3] >= fi.zmin_bits;
                 if (__any(open)) { visible = true; break; }
             }
@@ -462,7 +502,8 @@ __device__ bool enqueue_big(const FrameParams& P, uint32_t view, uint32_t id, co
     for (int32_t ry = ry0; ry <= ry1; ++ry)
         for (int32_t rx = rx0; rx <= rx1; ++rx) {
             it.region = ((uint32_t)ry << 16) | (uint32_t)rx;
-            P.big[k++] = it;
+            if (TOPO_CHK(P.counters, k < P.big_cap && rx >= 0 && ry >= 0 && rx * 64 < P.W && ry * 64 < P.H, 7u, k)) P.big[k] = it;
+            ++k;
         }
     return true;
 }
@@ -543,73 +584,16 @@ __device__ __forceinline__ bool classify_small(const FrameParams& P, const SVert
     return true;
 }
 
-// Stage 2: walk the pixel rows of one classified triangle.  A float estimate of each edge's crossing narrows a
-// row to its covered span (padded by a pixel either side); the exact integer test then decides every pixel, so
-// the estimate can only cost time, never change coverage.  Coverage, barycentrics and depth are the values
-// triangle_pixel() gives.
-__device__ __forceinline__ void raster_rows(FragList& fl, const Vis& vis, int32_t W, int32_t H, int32_t X0, int32_t Y0,
-                                            int32_t X1, int32_t Y1, int32_t X2, int32_t Y2, float z0, float z1, float z2,
-                                            uint32_t id) {
-    const int32_t mnx = min(X0, min(X1, X2)), mxx = max(X0, max(X1, X2));
-    const int32_t mny = min(Y0, min(Y1, Y2)), mxy = max(Y0, max(Y1, Y2));
-    const int32_t area2 = __mul24(X1 - X0, Y2 - Y0) - __mul24(Y1 - Y0, X2 - X0);
-    const int32_t px0 = max((mnx + 127) >> 8, 0), px1 = min((mxx - 128) >> 8, W - 1);
-    const int32_t py0 = max((mny + 127) >> 8, 0), py1 = min((mxy - 128) >> 8, H - 1);
-    // edges e0 = v1->v2, e1 = v2->v0, e2 = v0->v1
-    const int32_t dx0 = X2 - X1, dy0 = Y2 - Y1, dx1 = X0 - X2, dy1 = Y0 - Y2, dx2 = X1 - X0, dy2 = Y1 - Y0;
-    const int32_t b0 = ((dy0 > 0) || (dy0 == 0 && dx0 < 0)) ? 0 : -1;
-    const int32_t b1 = ((dy1 > 0) || (dy1 == 0 && dx1 < 0)) ? 0 : -1;
-    const int32_t b2 = ((dy2 > 0) || (dy2 == 0 && dx2 < 0)) ? 0 : -1;
-    const int32_t cx = px0 * 256 + 128, cy = py0 * 256 + 128;
-    int32_t r0 = __mul24(dy0, cx - X1) - __mul24(dx0, cy - Y1) + b0;      // biased: covered <=> all three >= 0
-    int32_t r1 = __mul24(dy1, cx - X2) - __mul24(dx1, cy - Y2) + b1;
-    int32_t r2 = __mul24(dy2, cx - X0) - __mul24(dx2, cy - Y0) + b2;
-    const int32_t m0 = dy0 * 256, m1 = dy1 * 256, m2 = dy2 * 256;
-    // hardware reciprocal (v_rcp_f32) is plenty for the span ESTIMATE
-    const float i0 = m0 ? __builtin_amdgcn_rcpf((float)m0) : 0.0f, i1 = m1 ? __builtin_amdgcn_rcpf((float)m1) : 0.0f,
-                i2 = m2 ? __builtin_amdgcn_rcpf((float)m2) : 0.0f;
-    const float iA = div_f(1.0f, (float)(-area2));
-    const float dz1 = z1 - z0, dz2 = z2 - z0;
-    const int32_t nx = px1 - px0;
-    for (int32_t py = py0; py <= py1; ++py) {
-        // conservative span [lo, hi] (relative to px0) from each edge's crossing -r/m
-        int32_t lo = 0, hi = nx;
-        bool dead = false;
-        {
-            const float q0 = -(float)r0 * i0, q1 = -(float)r1 * i1, q2 = -(float)r2 * i2;
-            if (m0 > 0) lo = max(lo, (int32_t)q0 - 1); else if (m0 < 0) hi = min(hi, (int32_t)q0 + 1); else dead |= r0 < 0;
-            if (m1 > 0) lo = max(lo, (int32_t)q1 - 1); else if (m1 < 0) hi = min(hi, (int32_t)q1 + 1); else dead |= r1 < 0;
-            if (m2 > 0) lo = max(lo, (int32_t)q2 - 1); else if (m2 < 0) hi = min(hi, (int32_t)q2 + 1); else dead |= r2 < 0;
-        }
-        if (!dead) {
-            int32_t F0 = r0 + m0 * lo, F1 = r1 + m1 * lo, F2 = r2 + m2 * lo;
-            for (int32_t k = lo; k <= hi; ++k) {
-                if ((F0 | F1 | F2) >= 0) {
-                    const float w1 = (float)(F1 - b1) * iA, w2 = (float)(F2 - b2) * iA;
-                    float z = fmaf(w1, dz1, fmaf(w2, dz2, z0));
-                    if (z < 1.0f) {
-                        if (z < 0.0f) z = 0.0f;
-                        frag_push(fl, vis, (uint32_t)(py * W + px0 + k), vis_key(z, id));
-                    }
-                }
-                F0 += m0;
-                F1 += m1;
-                F2 += m2;
-            }
-        }
-        r0 -= dx0 * 256;
-        r1 -= dx1 * 256;
-        r2 -= dx2 * 256;
-    }
-}
+// Stage 2 = raster_rows() (topo_pipeline.h), one listed triangle per lane, fragments into the per-wave LDS list.
 
 // Append this lane's triangle (if `push`) behind the `n` entries already listed; returns the new count.  Runs in
 // wave-uniform control flow: the slot is n + the lane's rank among the pushing lanes.
 __device__ __forceinline__ uint32_t tri_push(TriList& tl, uint32_t n, bool push, const SVert& s0, const SVert& s1, const SVert& s2,
-                                             uint32_t id) {
+                                             uint32_t id, uint32_t* vis_counters) {
     const uint64_t mask = __ballot(push);
     if (push) {
         const uint32_t slot = n + __popcll(mask & ((1ull << (threadIdx.x & 63)) - 1ull));
+        if (!TOPO_CHK(vis_counters, slot < kTriCap, 8u, slot)) return n;
         tl.X0[slot] = s0.X; tl.Y0[slot] = s0.Y; tl.X1[slot] = s1.X; tl.Y1[slot] = s1.Y; tl.X2[slot] = s2.X; tl.Y2[slot] = s2.Y;
         tl.z0[slot] = s0.z; tl.z1[slot] = s1.z; tl.z2[slot] = s2.z;
         tl.id[slot] = id;
@@ -625,7 +609,8 @@ __device__ __forceinline__ uint32_t tri_drain(TriList& tl, FragList& fl, const V
     const uint32_t take = min(n, 64u), base = n - take;
     if (lane < take) {
         const uint32_t e = base + lane;
-        raster_rows(fl, vis, W, H, tl.X0[e], tl.Y0[e], tl.X1[e], tl.Y1[e], tl.X2[e], tl.Y2[e], tl.z0[e], tl.z1[e], tl.z2[e], tl.id[e]);
+        raster_rows(W, H, tl.X0[e], tl.Y0[e], tl.X1[e], tl.Y1[e], tl.X2[e], tl.Y2[e], tl.z0[e], tl.z1[e], tl.z2[e], tl.id[e],
+                    [&](uint32_t pix, uint64_t key) { frag_push(fl, vis, pix, key); });
     }
     const uint32_t nfrag = min(fl.count, kFragCap);
     if (nfrag >= 64 || (flush && nfrag > 0)) {
@@ -696,6 +681,8 @@ __global__ __launch_bounds__(256, TOPO_RASTER_WAVES) void k_raster(FrameParams P
         const auto hcol = TOPO_GLOBAL_F32(t.heights) + (size_t)y0 * P.tile_w + (vcol ? vx : x0);   // global, not flat, loads
         // heights are prefetched four rows ahead (a rotating register window): one 244-B row read per wave is
         // too little to have in flight at a time
+        (void)TOPO_CHK(P.counters, rank < P.n_tiles && view_idx < P.n_views && y0 + nrows <= P.tile_h && (vcol ? vx : x0) < P.tile_w && nrows >= 1u, 9u,
+                       ((uint64_t)y0 << 32) | x0);
         float h0 = hcol[0];
         float h1 = nrows > 1 ? hcol[(size_t)1 * P.tile_w] : 0.0f;
         float h2 = nrows > 2 ? hcol[(size_t)2 * P.tile_w] : 0.0f;
@@ -748,7 +735,7 @@ __global__ __launch_bounds__(256, TOPO_RASTER_WAVES) void k_raster(FrameParams P
                             if (nnear != 3) enqueue_rare(P, view_idx, draw);
                         }   // else: guard band -> primitive discarded
                     }
-                    ntri = tri_push(tl, ntri, push, s0, s1, s2, draw << 1);
+                    ntri = tri_push(tl, ntri, push, s0, s1, s2, draw << 1, P.counters);
                     if (ntri >= 64) ntri = tri_drain(tl, fl, vis, P.W, P.H, ntri, false);
                 }
             }
@@ -770,6 +757,7 @@ __global__ __launch_bounds__(256) void k_raster_rare(FrameParams P) {
     for (uint32_t item = P.counters[7] + blockIdx.x * blockDim.x + threadIdx.x; item < count; item += gridDim.x * blockDim.x) {
         const RareItem ri = P.rare[item];
         const uint32_t rank = fastdiv(ri.draw, P.div_tris), tri = ri.draw - rank * P.tris_per_tile;
+        if (!TOPO_CHK(P.counters, rank < P.n_tiles && ri.view < P.n_views, 10u, ri.draw)) continue;
         const Vis vis = view_vis(P, ri.view);
         for (uint32_t fan = 0; fan < 2; ++fan) {
             ResolvedTri r;
@@ -787,44 +775,21 @@ __device__ __forceinline__ int32_t uni(int32_t v) { return __builtin_amdgcn_read
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)v); }
 __device__ __forceinline__ float unif(float v) { return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int32_t)__float_as_uint(v))); }
 
-// Up to four candidate fragments of one lane.  key == kVisClear marks "no fragment" (no real key equals it: ids
-// are < 0xFFFFFFFF and depths < 1.0).  With kPretest the current keys are read first, all four loads in flight
-// together, and only improving fragments issue an atomic; without it the atomics are issued blind (see vis_min:
-// the pre-test measured slower and is kept only as a build-time knob).
-#ifndef TOPO_BIG_PRETEST_SMALL
-#define TOPO_BIG_PRETEST_SMALL false
-#endif
-template <bool kPretest>
-__device__ __forceinline__ void vis_min4(const Vis& vis, const uint32_t pix[4], const uint64_t key[4]) {
-    if (!kPretest) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (key[k] != kVisClear) vis_min(vis, pix[k], key[k]);
-        return;
-    }
-    uint64_t cur[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-        cur[k] = key[k] != kVisClear ? __hip_atomic_load(vis.p + pix[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-        if (key[k] < cur[k]) vis_min(vis, pix[k], key[k]);
-}
-
 // One wave per BigItem: the item carries the snapped vertices, so every lane re-runs the exact integer setup
-// (wave-uniform) and the wave sweeps the item's 64x64 region in strips of four 8x8 px sub-chunks, one pixel per
-// lane and sub-chunk.  Triangles spanning < 64 px (all that k_raster enqueues) take the int32 form of the same
-// integers; the giants that come through k_raster_rare take the int64 form.
+// (wave-uniform: the item's fields are forced into scalar registers) and the wave sweeps the part of the triangle's
+// pixel box inside the item's 64x64 px region.  Triangles spanning < 64 px (all that k_raster enqueues) take the int32
+// form of the same integers (big_medium_lane), the giants that come through k_raster_rare the int64 form
+// (big_giant_lane); both are in topo_pipeline.h and run lane by lane on the CPU in the tests.  Fragments are issued
+// blind (no depth pre-test, see vis_min): only entries that carry a fragment (key != kVisClear) are dereferenced.
 __global__ __launch_bounds__(256) void k_raster_big(FrameParams P) {
     uint32_t count = P.counters[1];
     if (count > P.big_cap) count = P.big_cap;
     const uint32_t lane = threadIdx.x & 63;
-    const int32_t lx = (int32_t)(lane & 7), ly = (int32_t)(lane >> 3);
     const uint32_t wave_global = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wave_count = gridDim.x * 4;
     for (uint32_t item = P.counters[6] + wave_global; item < count; item += wave_count) {
         // The item is the same for the whole wave, but the compiler cannot use scalar loads for it (the queue is
         // written by other kernels through the same pointer type): say so field by field, and the integer setup
-        // below runs on the scalar unit instead of 64 times over on the vector one.
+        // runs on the scalar unit instead of 64 times over on the vector one.
         BigItem bi;
         {
             const BigItem& g = P.big[item];
@@ -835,110 +800,15 @@ __global__ __launch_bounds__(256) void k_raster_big(FrameParams P) {
         if (bi.id == kNoTri) continue;
         const Vis vis = view_vis(P, bi.view);
         const int32_t rx = (int32_t)(bi.region & 0xFFFFu), ry = (int32_t)(bi.region >> 16);
-        const int32_t X0 = bi.X[0], Y0 = bi.Y[0], X1 = bi.X[1], Y1 = bi.Y[1], X2 = bi.X[2], Y2 = bi.Y[2];
-        const int32_t mnx = min(X0, min(X1, X2)), mxx = max(X0, max(X1, X2));
-        const int32_t mny = min(Y0, min(Y1, Y2)), mxy = max(Y0, max(Y1, Y2));
-        if ((mxx - mnx) < (1 << 14) && (mxy - mny) < (1 << 14)) {
-            const int32_t area2 = (X1 - X0) * (Y2 - Y0) - (Y1 - Y0) * (X2 - X0);      // |factors| < 2^14: exact in int32
-            if (area2 >= 0) continue;
-            int32_t px0 = max((mnx + 127) >> 8, 0), px1 = min((mxx - 128) >> 8, P.W - 1);
-            int32_t py0 = max((mny + 127) >> 8, 0), py1 = min((mxy - 128) >> 8, P.H - 1);
-            px0 = max(px0, rx * 64); px1 = min(px1, rx * 64 + 63);
-            py0 = max(py0, ry * 64); py1 = min(py1, ry * 64 + 63);
-            const int32_t bw = px1 - px0 + 1, bh = py1 - py0 + 1;
-            if (bw <= 0 || bh <= 0) continue;
-            const int32_t dx0 = X2 - X1, dy0 = Y2 - Y1, dx1 = X0 - X2, dy1 = Y0 - Y2, dx2 = X1 - X0, dy2 = Y1 - Y0;
-            const int32_t b0 = ((dy0 > 0) || (dy0 == 0 && dx0 < 0)) ? 0 : -1;
-            const int32_t b1 = ((dy1 > 0) || (dy1 == 0 && dx1 < 0)) ? 0 : -1;
-            const int32_t b2 = ((dy2 > 0) || (dy2 == 0 && dx2 < 0)) ? 0 : -1;
-            // biased edge functions at the box's first pixel centre, and their steps per pixel in x (A) and y (-B);
-            // the box is at most 64 px wide and high, so every value below stays under 2^29
-            const int32_t cx0 = px0 * 256 + 128, cy0 = py0 * 256 + 128;
-            const int32_t R0 = dy0 * (cx0 - X1) - dx0 * (cy0 - Y1) + b0;
-            const int32_t R1 = dy1 * (cx0 - X2) - dx1 * (cy0 - Y2) + b1;
-            const int32_t R2 = dy2 * (cx0 - X0) - dx2 * (cy0 - Y0) + b2;
-            const int32_t A0 = dy0 * 256, A1 = dy1 * 256, A2 = dy2 * 256, B0 = dx0 * 256, B1 = dx1 * 256, B2 = dx2 * 256;
-            const float iA = div_f(1.0f, (float)(-area2));
-            const float z0 = bi.z[0], dz1 = bi.z[1] - bi.z[0], dz2 = bi.z[2] - bi.z[0];
-            // lanes tile the box row-major, the row length rounded up to a power of two: 8 x 8, 16 x 4, 32 x 2 or 64 x 1
-            const uint32_t sh = bw <= 8 ? 3u : bw <= 16 ? 4u : bw <= 32 ? 5u : 6u;
-            const int32_t u = (int32_t)(lane & ((1u << sh) - 1u)), v0 = (int32_t)(lane >> sh), rows = 64 >> sh;
-            int32_t F0 = R0 + __mul24(A0, u) - __mul24(B0, v0);
-            int32_t F1 = R1 + __mul24(A1, u) - __mul24(B1, v0);
-            int32_t F2 = R2 + __mul24(A2, u) - __mul24(B2, v0);
-            const int32_t S0 = B0 * rows, S1 = B1 * rows, S2 = B2 * rows;
-            uint32_t pixel = (uint32_t)((py0 + v0) * P.W + px0 + u);
-            const uint32_t pstep = (uint32_t)(rows * P.W);
-            const bool ucol = u < bw;
-            for (int32_t vb = 0; vb < bh; vb += 4 * rows) {
-                uint32_t pix[4];
-                uint64_t key[4];
+        if (!TOPO_CHK(P.counters, bi.view < P.n_views && rx * 64 < P.W && ry * 64 < P.H, 11u, bi.region)) continue;
+        if (spans_fit_int32(bi.X[0], bi.Y[0], bi.X[1], bi.Y[1], bi.X[2], bi.Y[2])) {
+            big_medium_lane(bi.X, bi.Y, bi.z, bi.id, P.W, P.H, rx, ry, lane, [&](const uint32_t pix[4], const uint64_t key[4]) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    key[k] = kVisClear;
-                    pix[k] = pixel;
-                    if (ucol && vb + k * rows + v0 < bh && (F0 | F1 | F2) >= 0) {
-                        const float w1 = (float)(F1 - b1) * iA, w2 = (float)(F2 - b2) * iA;
-                        float z = fmaf(w1, dz1, fmaf(w2, dz2, z0));
-                        if (z < 1.0f) {
-                            if (z < 0.0f) z = 0.0f;
-                            key[k] = vis_key(z, bi.id);
-                        }
-                    }
-                    F0 -= S0; F1 -= S1; F2 -= S2;
-                    pixel += pstep;
-                }
-                vis_min4<TOPO_BIG_PRETEST_SMALL>(vis, pix, key);
-            }
-            continue;
-        }
-        // Giants (a vertex pair >= 64 px apart): the 64-bit edge functions of triangle_setup, evaluated once per lane at
-        // its pixel of the first 8x8 sub-chunk and then stepped (8 px in x: + 2048 dy, 8 px in y: - 2048 dx), so a
-        // sub-chunk costs three 64-bit additions instead of six 64-bit multiplications.
-        SVert s[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { s[k].X = bi.X[k]; s[k].Y = bi.Y[k]; s[k].z = bi.z[k]; s[k].flag = kVtxOk; }
-        TriSetup ts;
-        if (!triangle_setup(s[0], s[1], s[2], P.W, P.H, ts)) continue;
-        const int32_t bx0 = max(ts.px0, rx * 64), bx1 = min(ts.px1, rx * 64 + 63);
-        const int32_t by0 = max(ts.py0, ry * 64), by1 = min(ts.py1, ry * 64 + 63);
-        if (bx0 > bx1 || by0 > by1) continue;
-        const int32_t sx0 = bx0 & ~7, sy0 = by0 & ~7;
-        const int64_t cx = (int64_t)(sx0 + lx) * 256 + 128, cy = (int64_t)(sy0 + ly) * 256 + 128;
-        int64_t Fr0 = ts.dy[0] * (cx - ts.ax[0]) - ts.dx[0] * (cy - ts.ay[0]) + ts.bias[0];   // biased: covered <=> all >= 0
-        int64_t Fr1 = ts.dy[1] * (cx - ts.ax[1]) - ts.dx[1] * (cy - ts.ay[1]) + ts.bias[1];
-        int64_t Fr2 = ts.dy[2] * (cx - ts.ax[2]) - ts.dx[2] * (cy - ts.ay[2]) + ts.bias[2];
-        const int64_t ax0 = ts.dy[0] * 2048, ax1 = ts.dy[1] * 2048, ax2 = ts.dy[2] * 2048;
-        const int64_t ay0 = ts.dx[0] * 2048, ay1 = ts.dx[1] * 2048, ay2 = ts.dx[2] * 2048;
-        // barycentric numerators of covered pixels are in [0, |area2|]: below 2^48 (any triangle under ~46000 px
-        // across) the int64 -> f32 conversion is one fma of two exact 24-bit halves, the same single rounding
-        const bool narrow = -((X1 - (int64_t)X0) * (Y2 - (int64_t)Y0) - (Y1 - (int64_t)Y0) * (X2 - (int64_t)X0)) < (1ll << 48);
-        const int32_t b1 = (int32_t)ts.bias[1], b2 = (int32_t)ts.bias[2];
-        for (int32_t sy = sy0; sy <= by1; sy += 8) {
-            int64_t F0 = Fr0, F1 = Fr1, F2 = Fr2;
-            const int32_t py = sy + ly;
-            const bool rowin = py >= by0 && py <= by1;
-            for (int32_t sx = sx0; sx <= bx1; sx += 8) {
-                const int32_t px = sx + lx;
-                if (rowin && px >= bx0 && px <= bx1 && (F0 | F1 | F2) >= 0) {
-                    const int64_t U1 = F1 - b1, U2 = F2 - b2;
-                    float f1, f2;
-                    if (narrow) {
-                        f1 = fmaf((float)(int32_t)(U1 >> 24), 16777216.0f, (float)(int32_t)((uint32_t)U1 & 0xFFFFFFu));
-                        f2 = fmaf((float)(int32_t)(U2 >> 24), 16777216.0f, (float)(int32_t)((uint32_t)U2 & 0xFFFFFFu));
-                    } else {
-                        f1 = (float)U1;
-                        f2 = (float)U2;
-                    }
-                    float z = fmaf(f1 * ts.iA, ts.dz1, fmaf(f2 * ts.iA, ts.dz2, ts.z0));
-                    if (z < 1.0f) {
-                        if (z < 0.0f) z = 0.0f;
-                        vis_min(vis, (size_t)py * P.W + px, vis_key(z, bi.id));
-                    }
-                }
-                F0 += ax0; F1 += ax1; F2 += ax2;
-            }
-            Fr0 -= ay0; Fr1 -= ay1; Fr2 -= ay2;
+                for (int k = 0; k < 4; ++k)
+                    if (key[k] != kVisClear) vis_min(vis, pix[k], key[k]);
+            });
+        } else {
+            big_giant_lane(bi.X, bi.Y, bi.z, bi.id, P.W, P.H, rx, ry, lane, [&](size_t pix, uint64_t key) { vis_min(vis, pix, key); });
         }
     }
 }
@@ -977,7 +847,7 @@ __global__ __launch_bounds__(256, TOPO_RESOLVE_WGS) void k_resolve(FrameParams P
         const int32_t x0 = bx > 0 ? bx - 1 : 0, x1 = bx + 64 < P.W ? bx + 64 : P.W - 1;
         const size_t first = (size_t)(vis - P.vis) + (size_t)y * P.W;
         const size_t seg = ((first + x0) >> 6) + k;
-        terrain = seg <= ((first + x1) >> 6) && P.dirty[seg] != 0;
+        terrain = seg <= ((first + x1) >> 6) && TOPO_CHK(P.counters, seg < (((size_t)P.n_views * P.W * P.H + 63) >> 6), 12u, seg) && P.dirty[seg] != 0;
     }
     if (__syncthreads_or(terrain) == 0) {        // workgroup-uniform: write the cleared texel and depth 1
         const int32_t px = bx + (int32_t)(threadIdx.x & 63);
@@ -1039,7 +909,8 @@ __global__ __launch_bounds__(256, TOPO_RESOLVE_WGS) void k_resolve(FrameParams P
             const uint32_t draw = id >> 1, fan = id & 1u;
             const uint32_t rank = fastdiv(draw, P.div_tris), tri = draw - rank * P.tris_per_tile;
             f3 wpos, wnrm;
-            if (resolve_varyings(P.tiles[rank], P.tile_w, P.div_hm1, P.tile_h - 1, view, P.W, P.H, tri, fan, s_ndec, px, py, wpos, wnrm)) {
+            if (TOPO_CHK(P.counters, rank < P.n_tiles, 13u, id) &&
+                resolve_varyings(P.tiles[rank], P.tile_w, P.div_hm1, P.tile_h - 1, view, P.W, P.H, tri, fan, s_ndec, px, py, wpos, wnrm)) {
                 const f3 sun = {view.sun[0], view.sun[1], view.sun[2]};
                 shade_fragment(view.view_mode, sun, view.cam_x, view.cam_y, (float)px + 0.5f, (float)py + 0.5f, wpos, wnrm, lin);
             }
@@ -1211,25 +1082,31 @@ void launch_cull(const FrameParams& p, hipStream_t s) {
 
 // Persistent-style grids: exactly as many workgroups as are resident at once (occupancy x CUs), each wave striding
 // over its queue, so there is no partially filled second round of workgroups.
-template <typename K>
+// The size is a property of (kernel, device): cached per device id, so one process can drive several GPUs.
+template <int kSite, typename K>
 static unsigned resident_grid(K kernel, unsigned fallback) {
+    constexpr int kMaxDev = 64;
+    static std::atomic<unsigned> cache[kMaxDev];      // 0 = not computed yet; one array per call site (kSite)
     int dev = 0, cus = 0, per_cu = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return fallback;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return fallback;
+    if (unsigned g = cache[dev].load(std::memory_order_relaxed)) return g;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return fallback;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu <= 0) return fallback;
-    return (unsigned)(cus * per_cu);
+    const unsigned g = (unsigned)(cus * per_cu);
+    cache[dev].store(g, std::memory_order_relaxed);
+    return g;
 }
 
 void launch_raster(const FrameParams& p, int phase, hipStream_t s) {
     if (p.n_tiles == 0) return;
-    static const unsigned grid = resident_grid(k_raster, 256 * 5);
+    const unsigned grid = resident_grid<0>(k_raster, 256 * 5);
     hipLaunchKernelGGL(k_raster, dim3(grid), dim3(256), 0, s, p, phase);
 }
 
 
 void launch_occlusion(const FrameParams& p, hipStream_t s) {
     if (p.n_tiles == 0) return;
-    static const unsigned grid = resident_grid(k_occlusion, 256 * 8);
+    const unsigned grid = resident_grid<1>(k_occlusion, 256 * 8);
     hipLaunchKernelGGL(k_occlusion, dim3(grid), dim3(256), 0, s, p);
 }
 
@@ -1240,7 +1117,7 @@ void launch_raster_rare(const FrameParams& p, hipStream_t s) {
 
 void launch_raster_big(const FrameParams& p, hipStream_t s) {
     if (p.n_tiles == 0) return;
-    static const unsigned grid = resident_grid(k_raster_big, 256 * 4);
+    const unsigned grid = resident_grid<2>(k_raster_big, 256 * 4);
     hipLaunchKernelGGL(k_raster_big, dim3(grid), dim3(256), 0, s, p);
 }
 

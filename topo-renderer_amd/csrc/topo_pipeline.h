@@ -226,6 +226,205 @@ TOPO_HD bool triangle_bary(const SVert& s0, const SVert& s1, const SVert& s2, in
 
 TOPO_HD uint64_t vis_key(float z, uint32_t id) { return ((uint64_t)f_bits(z) << 32) | id; }
 
+// ---- lane bodies of the raster kernels ---------------------------------------------------------------------
+// The pixel walks of k_raster (stage 2) and k_raster_big are written as plain functions of the lane index with the
+// fragment sink passed in, so that tests/host_emul.cpp can run every lane of a work item on the CPU with a
+// bounds-checking sink (tests/test_emul_cpu.py::test_big_item_lanes_*, test_raster_rows_*): each fragment must lie
+// inside the target and inside the item's region, be emitted exactly once, and carry the key triangle_pixel() gives.
+// (Round 1 lost a GPU box to an out-of-range visibility index in an uncommitted variant of the lane tiling below:
+// DESIGN.md "The exp_direct fault".)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TOPO_RCP_EST(x) __builtin_amdgcn_rcpf(x)     // span ESTIMATES only: the exact integers decide every pixel
+#else
+#define TOPO_RCP_EST(x) (1.0f / (x))
+#endif
+
+// A triangle whose snapped vertices span < 2^14 sub-pixels (64 px) in x and y: every edge-function product fits int32.
+TOPO_HD bool spans_fit_int32(int32_t X0, int32_t Y0, int32_t X1, int32_t Y1, int32_t X2, int32_t Y2) {
+    const int32_t mnx = X0 < X1 ? (X0 < X2 ? X0 : X2) : (X1 < X2 ? X1 : X2), mxx = X0 > X1 ? (X0 > X2 ? X0 : X2) : (X1 > X2 ? X1 : X2);
+    const int32_t mny = Y0 < Y1 ? (Y0 < Y2 ? Y0 : Y2) : (Y1 < Y2 ? Y1 : Y2), mxy = Y0 > Y1 ? (Y0 > Y2 ? Y0 : Y2) : (Y1 > Y2 ? Y1 : Y2);
+    return (mxx - mnx) < (1 << 14) && (mxy - mny) < (1 << 14);
+}
+
+// Stage 2 of k_raster: walk the pixel rows of one classified triangle (spans_fit_int32).  A float estimate of each
+// edge's crossing narrows a row to its covered span (padded by a pixel either side); the exact integer test then
+// decides every pixel, so the estimate can only cost time, never change coverage.  Coverage, barycentrics and depth
+// are the values triangle_pixel() gives.  emit(pixel index, key).
+template <typename Emit>
+TOPO_HD void raster_rows(int32_t W, int32_t H, int32_t X0, int32_t Y0, int32_t X1, int32_t Y1, int32_t X2, int32_t Y2, float z0,
+                         float z1, float z2, uint32_t id, Emit&& emit) {
+    const int32_t mnx = X0 < X1 ? (X0 < X2 ? X0 : X2) : (X1 < X2 ? X1 : X2), mxx = X0 > X1 ? (X0 > X2 ? X0 : X2) : (X1 > X2 ? X1 : X2);
+    const int32_t mny = Y0 < Y1 ? (Y0 < Y2 ? Y0 : Y2) : (Y1 < Y2 ? Y1 : Y2), mxy = Y0 > Y1 ? (Y0 > Y2 ? Y0 : Y2) : (Y1 > Y2 ? Y1 : Y2);
+    const int32_t area2 = TOPO_MUL24(X1 - X0, Y2 - Y0) - TOPO_MUL24(Y1 - Y0, X2 - X0);
+    const int32_t bx0 = (mnx + 127) >> 8, bx1 = (mxx - 128) >> 8, by0 = (mny + 127) >> 8, by1 = (mxy - 128) >> 8;
+    const int32_t px0 = bx0 > 0 ? bx0 : 0, px1 = bx1 < W - 1 ? bx1 : W - 1;
+    const int32_t py0 = by0 > 0 ? by0 : 0, py1 = by1 < H - 1 ? by1 : H - 1;
+    // edges e0 = v1->v2, e1 = v2->v0, e2 = v0->v1
+    const int32_t dx0 = X2 - X1, dy0 = Y2 - Y1, dx1 = X0 - X2, dy1 = Y0 - Y2, dx2 = X1 - X0, dy2 = Y1 - Y0;
+    const int32_t b0 = ((dy0 > 0) || (dy0 == 0 && dx0 < 0)) ? 0 : -1;
+    const int32_t b1 = ((dy1 > 0) || (dy1 == 0 && dx1 < 0)) ? 0 : -1;
+    const int32_t b2 = ((dy2 > 0) || (dy2 == 0 && dx2 < 0)) ? 0 : -1;
+    const int32_t cx = px0 * 256 + 128, cy = py0 * 256 + 128;
+    int32_t r0 = TOPO_MUL24(dy0, cx - X1) - TOPO_MUL24(dx0, cy - Y1) + b0;      // biased: covered <=> all three >= 0
+    int32_t r1 = TOPO_MUL24(dy1, cx - X2) - TOPO_MUL24(dx1, cy - Y2) + b1;
+    int32_t r2 = TOPO_MUL24(dy2, cx - X0) - TOPO_MUL24(dx2, cy - Y0) + b2;
+    const int32_t m0 = dy0 * 256, m1 = dy1 * 256, m2 = dy2 * 256;
+    // hardware reciprocal (v_rcp_f32) is plenty for the span ESTIMATE
+    const float i0 = m0 ? TOPO_RCP_EST((float)m0) : 0.0f, i1 = m1 ? TOPO_RCP_EST((float)m1) : 0.0f, i2 = m2 ? TOPO_RCP_EST((float)m2) : 0.0f;
+    const float iA = div_f(1.0f, (float)(-area2));
+    const float dz1 = z1 - z0, dz2 = z2 - z0;
+    const int32_t nx = px1 - px0;
+    for (int32_t py = py0; py <= py1; ++py) {
+        // conservative span [lo, hi] (relative to px0, always inside [0, nx]) from each edge's crossing -r/m
+        int32_t lo = 0, hi = nx;
+        bool dead = false;
+        {
+            const float q0 = -(float)r0 * i0, q1 = -(float)r1 * i1, q2 = -(float)r2 * i2;
+            if (m0 > 0) { const int32_t c = (int32_t)q0 - 1; lo = lo > c ? lo : c; } else if (m0 < 0) { const int32_t c = (int32_t)q0 + 1; hi = hi < c ? hi : c; } else dead |= r0 < 0;
+            if (m1 > 0) { const int32_t c = (int32_t)q1 - 1; lo = lo > c ? lo : c; } else if (m1 < 0) { const int32_t c = (int32_t)q1 + 1; hi = hi < c ? hi : c; } else dead |= r1 < 0;
+            if (m2 > 0) { const int32_t c = (int32_t)q2 - 1; lo = lo > c ? lo : c; } else if (m2 < 0) { const int32_t c = (int32_t)q2 + 1; hi = hi < c ? hi : c; } else dead |= r2 < 0;
+        }
+        if (!dead) {
+            int32_t F0 = r0 + m0 * lo, F1 = r1 + m1 * lo, F2 = r2 + m2 * lo;
+            for (int32_t k = lo; k <= hi; ++k) {
+                if ((F0 | F1 | F2) >= 0) {
+                    const float w1 = (float)(F1 - b1) * iA, w2 = (float)(F2 - b2) * iA;
+                    float z = fmaf(w1, dz1, fmaf(w2, dz2, z0));
+                    if (z < 1.0f) {
+                        if (z < 0.0f) z = 0.0f;
+                        emit((uint32_t)(py * W + px0 + k), vis_key(z, id));
+                    }
+                }
+                F0 += m0;
+                F1 += m1;
+                F2 += m2;
+            }
+        }
+        r0 -= dx0 * 256;
+        r1 -= dx1 * 256;
+        r2 -= dx2 * 256;
+    }
+}
+
+// k_raster_big, medium triangles (spans_fit_int32): the part of the triangle's pixel box inside region (rx, ry)
+// (64 px units) is tiled row-major by the wave's 64 lanes, the row length rounded up to 8/16/32/64; lane `lane`
+// visits the pixels (px0 + u, py0 + v0 + k*rows) and hands them over four at a time: emit4(pix[4], key[4]).
+// CONTRACT: an entry with key == kVisClear carries no fragment and its pix[] is NOT a valid index (lanes beyond
+// the box keep stepping their pixel counter) -- a sink must not touch pix[k] without testing key[k].
+template <typename Emit4>
+TOPO_HD void big_medium_lane(const int32_t X[3], const int32_t Y[3], const float zv[3], uint32_t id, int32_t W, int32_t H,
+                             int32_t rx, int32_t ry, uint32_t lane, Emit4&& emit4) {
+    const int32_t X0 = X[0], Y0 = Y[0], X1 = X[1], Y1 = Y[1], X2 = X[2], Y2 = Y[2];
+    const int32_t mnx = X0 < X1 ? (X0 < X2 ? X0 : X2) : (X1 < X2 ? X1 : X2), mxx = X0 > X1 ? (X0 > X2 ? X0 : X2) : (X1 > X2 ? X1 : X2);
+    const int32_t mny = Y0 < Y1 ? (Y0 < Y2 ? Y0 : Y2) : (Y1 < Y2 ? Y1 : Y2), mxy = Y0 > Y1 ? (Y0 > Y2 ? Y0 : Y2) : (Y1 > Y2 ? Y1 : Y2);
+    const int32_t area2 = (X1 - X0) * (Y2 - Y0) - (Y1 - Y0) * (X2 - X0);      // |factors| < 2^14: exact in int32
+    if (area2 >= 0) return;
+    int32_t px0 = (mnx + 127) >> 8, px1 = (mxx - 128) >> 8, py0 = (mny + 127) >> 8, py1 = (mxy - 128) >> 8;
+    px0 = px0 > 0 ? px0 : 0; px1 = px1 < W - 1 ? px1 : W - 1;
+    py0 = py0 > 0 ? py0 : 0; py1 = py1 < H - 1 ? py1 : H - 1;
+    px0 = px0 > rx * 64 ? px0 : rx * 64; px1 = px1 < rx * 64 + 63 ? px1 : rx * 64 + 63;
+    py0 = py0 > ry * 64 ? py0 : ry * 64; py1 = py1 < ry * 64 + 63 ? py1 : ry * 64 + 63;
+    const int32_t bw = px1 - px0 + 1, bh = py1 - py0 + 1;
+    if (bw <= 0 || bh <= 0) return;
+    const int32_t dx0 = X2 - X1, dy0 = Y2 - Y1, dx1 = X0 - X2, dy1 = Y0 - Y2, dx2 = X1 - X0, dy2 = Y1 - Y0;
+    const int32_t b0 = ((dy0 > 0) || (dy0 == 0 && dx0 < 0)) ? 0 : -1;
+    const int32_t b1 = ((dy1 > 0) || (dy1 == 0 && dx1 < 0)) ? 0 : -1;
+    const int32_t b2 = ((dy2 > 0) || (dy2 == 0 && dx2 < 0)) ? 0 : -1;
+    // biased edge functions at the box's first pixel centre, and their steps per pixel in x (A) and y (-B);
+    // the box is at most 64 px wide and high, so every value below stays under 2^29
+    const int32_t cx0 = px0 * 256 + 128, cy0 = py0 * 256 + 128;
+    const int32_t R0 = dy0 * (cx0 - X1) - dx0 * (cy0 - Y1) + b0;
+    const int32_t R1 = dy1 * (cx0 - X2) - dx1 * (cy0 - Y2) + b1;
+    const int32_t R2 = dy2 * (cx0 - X0) - dx2 * (cy0 - Y0) + b2;
+    const int32_t A0 = dy0 * 256, A1 = dy1 * 256, A2 = dy2 * 256, B0 = dx0 * 256, B1 = dx1 * 256, B2 = dx2 * 256;
+    const float iA = div_f(1.0f, (float)(-area2));
+    const float z0 = zv[0], dz1 = zv[1] - zv[0], dz2 = zv[2] - zv[0];
+    // lanes tile the box row-major, the row length rounded up to a power of two: 8 x 8, 16 x 4, 32 x 2 or 64 x 1
+    const uint32_t sh = bw <= 8 ? 3u : bw <= 16 ? 4u : bw <= 32 ? 5u : 6u;
+    const int32_t u = (int32_t)(lane & ((1u << sh) - 1u)), v0 = (int32_t)(lane >> sh), rows = 64 >> sh;
+    int32_t F0 = R0 + TOPO_MUL24(A0, u) - TOPO_MUL24(B0, v0);
+    int32_t F1 = R1 + TOPO_MUL24(A1, u) - TOPO_MUL24(B1, v0);
+    int32_t F2 = R2 + TOPO_MUL24(A2, u) - TOPO_MUL24(B2, v0);
+    const int32_t S0 = B0 * rows, S1 = B1 * rows, S2 = B2 * rows;
+    uint32_t pixel = (uint32_t)((py0 + v0) * W + px0 + u);
+    const uint32_t pstep = (uint32_t)(rows * W);
+    const bool ucol = u < bw;
+    for (int32_t vb = 0; vb < bh; vb += 4 * rows) {
+        uint32_t pix[4];
+        uint64_t key[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            key[k] = kVisClear;
+            pix[k] = pixel;
+            if (ucol && vb + k * rows + v0 < bh && (F0 | F1 | F2) >= 0) {
+                const float w1 = (float)(F1 - b1) * iA, w2 = (float)(F2 - b2) * iA;
+                float z = fmaf(w1, dz1, fmaf(w2, dz2, z0));
+                if (z < 1.0f) {
+                    if (z < 0.0f) z = 0.0f;
+                    key[k] = vis_key(z, id);
+                }
+            }
+            F0 -= S0; F1 -= S1; F2 -= S2;
+            pixel += pstep;
+        }
+        emit4(pix, key);
+    }
+}
+
+// k_raster_big, giants (a vertex pair >= 64 px apart): the 64-bit edge functions of triangle_setup, evaluated once per
+// lane at its pixel of the first 8x8 sub-chunk of region (rx, ry) and then stepped (8 px in x: + 2048 dy, 8 px in y:
+// - 2048 dx), so a sub-chunk costs three 64-bit additions instead of six 64-bit multiplications.  emit(pixel index, key).
+template <typename Emit>
+TOPO_HD void big_giant_lane(const int32_t X[3], const int32_t Y[3], const float zv[3], uint32_t id, int32_t W, int32_t H,
+                            int32_t rx, int32_t ry, uint32_t lane, Emit&& emit) {
+    SVert s[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { s[k].X = X[k]; s[k].Y = Y[k]; s[k].z = zv[k]; s[k].flag = kVtxOk; }
+    TriSetup ts;
+    if (!triangle_setup(s[0], s[1], s[2], W, H, ts)) return;
+    const int32_t bx0 = ts.px0 > rx * 64 ? ts.px0 : rx * 64, bx1 = ts.px1 < rx * 64 + 63 ? ts.px1 : rx * 64 + 63;
+    const int32_t by0 = ts.py0 > ry * 64 ? ts.py0 : ry * 64, by1 = ts.py1 < ry * 64 + 63 ? ts.py1 : ry * 64 + 63;
+    if (bx0 > bx1 || by0 > by1) return;
+    const int32_t lx = (int32_t)(lane & 7), ly = (int32_t)(lane >> 3);
+    const int32_t sx0 = bx0 & ~7, sy0 = by0 & ~7;
+    const int64_t cx = (int64_t)(sx0 + lx) * 256 + 128, cy = (int64_t)(sy0 + ly) * 256 + 128;
+    int64_t Fr0 = ts.dy[0] * (cx - ts.ax[0]) - ts.dx[0] * (cy - ts.ay[0]) + ts.bias[0];   // biased: covered <=> all >= 0
+    int64_t Fr1 = ts.dy[1] * (cx - ts.ax[1]) - ts.dx[1] * (cy - ts.ay[1]) + ts.bias[1];
+    int64_t Fr2 = ts.dy[2] * (cx - ts.ax[2]) - ts.dx[2] * (cy - ts.ay[2]) + ts.bias[2];
+    const int64_t ax0 = ts.dy[0] * 2048, ax1 = ts.dy[1] * 2048, ax2 = ts.dy[2] * 2048;
+    const int64_t ay0 = ts.dx[0] * 2048, ay1 = ts.dx[1] * 2048, ay2 = ts.dx[2] * 2048;
+    // barycentric numerators of covered pixels are in [0, |area2|]: below 2^48 (any triangle under ~46000 px
+    // across) the int64 -> f32 conversion is one fma of two exact 24-bit halves, the same single rounding
+    const bool narrow = -((X[1] - (int64_t)X[0]) * (Y[2] - (int64_t)Y[0]) - (Y[1] - (int64_t)Y[0]) * (X[2] - (int64_t)X[0])) < (1ll << 48);
+    const int32_t b1 = (int32_t)ts.bias[1], b2 = (int32_t)ts.bias[2];
+    for (int32_t sy = sy0; sy <= by1; sy += 8) {
+        int64_t F0 = Fr0, F1 = Fr1, F2 = Fr2;
+        const int32_t py = sy + ly;
+        const bool rowin = py >= by0 && py <= by1;
+        for (int32_t sx = sx0; sx <= bx1; sx += 8) {
+            const int32_t px = sx + lx;
+            if (rowin && px >= bx0 && px <= bx1 && (F0 | F1 | F2) >= 0) {
+                const int64_t U1 = F1 - b1, U2 = F2 - b2;
+                float f1, f2;
+                if (narrow) {
+                    f1 = fmaf((float)(int32_t)(U1 >> 24), 16777216.0f, (float)(int32_t)((uint32_t)U1 & 0xFFFFFFu));
+                    f2 = fmaf((float)(int32_t)(U2 >> 24), 16777216.0f, (float)(int32_t)((uint32_t)U2 & 0xFFFFFFu));
+                } else {
+                    f1 = (float)U1;
+                    f2 = (float)U2;
+                }
+                float z = fmaf(f1 * ts.iA, ts.dz1, fmaf(f2 * ts.iA, ts.dz2, ts.z0));
+                if (z < 1.0f) {
+                    if (z < 0.0f) z = 0.0f;
+                    emit((size_t)py * W + px, vis_key(z, id));
+                }
+            }
+            F0 += ax0; F1 += ax1; F2 += ax2;
+        }
+        Fr0 -= ay0; Fr1 -= ay1; Fr2 -= ay2;
+    }
+}
+
 // ---- near-plane clipping of one triangle -------------------------------------------------------------
 // Sutherland-Hodgman against z_clip >= 0, intersections always computed from the inside vertex towards the
 // outside one (t = z_in / (z_in - z_out)), output fan-triangulated from the first emitted vertex.
