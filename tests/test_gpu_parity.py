@@ -932,3 +932,31 @@ def test_bounds_checked_build_is_clean_and_identical(topo):
         assert not c["bounds_violation"], f"{name}: out-of-range index at site {c['bounds_site']}, value {c['bounds_value']}"
         assert c["sha"] == want["cases"][name]["sha"], f"{name}: the checked build renders a different frame"
         assert c["status"] == want["cases"][name]["status"]
+
+
+@pytest.mark.parametrize("tile,n,split", [(24, 4, 15000.0), (96, 3, 30000.0), (300, 2, 20000.0), (720, 2, 20000.0)])
+def test_occlusion_filter_is_conservative_on_coarse_tiles(topo, orc, tile, n, split):
+    """The far-block slab of the occlusion filter is flat-faced; the patch of a coarse tile's block bulges out of it by its
+    sagitta (hundreds of metres when a 60 x 15 cell block spans a degree).  k_block_minmax measures that: blocks beyond the
+    1 m allowance are never filtered, finer ones get the sagitta added to the slab.  Filter on == filter off == oracle."""
+    sc = Scene(tile, n, n, vfrac=(0.08, 0.07), eye_dh=900.0)
+    W, H = 256, 128
+    g, o = both(topo, orc, W, H)
+    sc.load(g)
+    sc.load(o)
+    pu = topo.post_uniforms(W, H)
+    tested = 0
+    for yaw, pitch in ((45, 4), (20, 1), (70, 8)):
+        u = sc.uniforms(W, H, yaw, pitch, 50, 0)
+        g.update(W, H, u, pu)
+        o.update(W, H, u, pu)
+        ref = o.render()
+        g.set_occlusion_split(split)
+        assert_same_frame(g.render(), ref, f"tile {tile} split {split} yaw {yaw}")
+        tested += g.counters()["far_tested"]
+        g.set_occlusion_split(0.0)
+        assert_same_frame(g.render(), ref, f"tile {tile} filter off yaw {yaw}")
+    if tile <= 300:
+        assert tested == 0          # sagitta 206 m / 53 m / 5.5 m: beyond the allowance, never filtered
+    else:
+        assert tested > 0           # 720-px tiles: 0.95 m -- filtered, with the sagitta added to the slab

@@ -1,0 +1,232 @@
+// tools/calib.hip -- calibration micro-kernels for the numbers bench.py's roofline blocks are priced against (gfx950).
+//
+//   tools/_build/calib hbm    known-byte streaming kernels in the access widths this path uses, to be run under
+//                             `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes):
+//                             the ratio known / counted per kernel is the correction factor for that width
+//                             (MI355X_MICROARCH.md: FETCH_SIZE is only calibrated for 16 B/lane reads: x2).
+//   tools/_build/calib valu   issue cost (shader cycles per wave64 instruction per SIMD) of the vector-ALU instruction
+//                             classes k_resolve / k_normals_interior are made of, at 1 and at 8 waves per SIMD, from
+//                             s_memtime around long independent instruction streams.  Prints one JSON line.
+//
+// Build: hipcc --offload-arch=gfx950 -O2 -o tools/_build/calib tools/calib.hip      (tools/build_calib.sh)
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#define CK(x)                                                                                   \
+    do {                                                                                        \
+        hipError_t e_ = (x);                                                                    \
+        if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } \
+    } while (0)
+
+// ---- HBM counter calibration ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void cal_read(const T* __restrict__ in, size_t n, uint32_t* __restrict__ sink) {
+    uint32_t acc = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const T v = in[i];
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(&v);
+#pragma unroll
+        for (unsigned k = 0; k < sizeof(T) / 4; ++k) acc ^= w[k];
+    }
+    if (acc == 0x12345678u) sink[0] = acc;      // never true for the test pattern; keeps the loads alive
+}
+// k_resolve's read pattern: a (16+2) x (64+2) tile of 8-byte keys per workgroup out of a W x H image, clamp-to-edge
+__global__ __launch_bounds__(256) void cal_read8_tile(const uint64_t* __restrict__ in, int W, int H, uint32_t* __restrict__ sink) {
+    const int bx = blockIdx.x * 64, by = blockIdx.y * 16;
+    uint32_t acc = 0;
+    for (int idx = threadIdx.x; idx < 18 * 66; idx += 256) {
+        const int ly = idx / 66, lx = idx - ly * 66;
+        int x = bx + lx - 1, y = by + ly - 1;
+        x = x < 0 ? 0 : (x > W - 1 ? W - 1 : x);
+        y = y < 0 ? 0 : (y > H - 1 ? H - 1 : y);
+        const uint64_t v = in[(size_t)blockIdx.z * W * H + (size_t)y * W + x];
+        acc ^= (uint32_t)v ^ (uint32_t)(v >> 32);
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void cal_write(T* __restrict__ out, size_t n, T v) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = v;
+}
+// the raster kernels' sink: one blind 64-bit atomic min per lane, lanes of a wave on consecutive keys
+__global__ __launch_bounds__(256) void cal_atomic8(uint64_t* __restrict__ out, size_t n, uint64_t v) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        atomicMin(reinterpret_cast<unsigned long long*>(out + i), (unsigned long long)(v + i));
+}
+
+static void run_hbm() {
+    const size_t bytes = (size_t)1 << 30;      // 1 GiB: four times the 256 MiB Infinity Cache
+    void *a = nullptr, *b = nullptr;
+    uint32_t* sink = nullptr;
+    CK(hipMalloc(&a, bytes));
+    CK(hipMalloc(&b, bytes));
+    CK(hipMalloc((void**)&sink, 64));
+    CK(hipMemset(a, 0x5A, bytes));
+    CK(hipMemset(b, 0xFF, bytes));
+    CK(hipDeviceSynchronize());
+    const int reps = 3;
+    for (int r = 0; r < reps; ++r) {
+        hipLaunchKernelGGL(cal_read<uint32_t>, dim3(8192), dim3(256), 0, 0, (const uint32_t*)a, bytes / 4, sink);
+        hipLaunchKernelGGL(cal_write<uint32_t>, dim3(8192), dim3(256), 0, 0, (uint32_t*)b, bytes / 4, 0xA5A5A5A5u);      // flushes `a` out of the caches
+        hipLaunchKernelGGL(cal_read<uint64_t>, dim3(8192), dim3(256), 0, 0, (const uint64_t*)a, bytes / 8, sink);
+        hipLaunchKernelGGL(cal_write<uint64_t>, dim3(8192), dim3(256), 0, 0, (uint64_t*)b, bytes / 8, 0xA5A5A5A5A5A5A5A5ull);
+        hipLaunchKernelGGL(cal_read<uint4>, dim3(8192), dim3(256), 0, 0, (const uint4*)a, bytes / 16, sink);
+        hipLaunchKernelGGL(cal_write<uint4>, dim3(8192), dim3(256), 0, 0, (uint4*)b, bytes / 16, make_uint4(1, 2, 3, 4));
+        // 8 views of 2048 x 4096 keys = 512 MiB, the c4 visibility buffer
+        hipLaunchKernelGGL(cal_read8_tile, dim3(2048 / 64, 4096 / 16, 8), dim3(256), 0, 0, (const uint64_t*)a, 2048, 4096, sink);
+        hipLaunchKernelGGL(cal_atomic8, dim3(8192), dim3(256), 0, 0, (uint64_t*)b, bytes / 8, 7ull);
+    }
+    CK(hipDeviceSynchronize());
+    printf("{\"hbm_calibration_bytes\": {\"cal_read<unsigned int>\": %zu, \"cal_read<unsigned long>\": %zu, \"cal_read<HIP_vector_type<unsigned int, 4u>>\": %zu, "
+           "\"cal_read8_tile\": %zu, \"cal_write<unsigned int>\": %zu, \"cal_write<unsigned long>\": %zu, \"cal_write<HIP_vector_type<unsigned int, 4u>>\": %zu, "
+           "\"cal_atomic8\": %zu}}\n",
+           bytes, bytes, bytes, (size_t)8 * 2048 * 4096 * 8, bytes, bytes, bytes, bytes);
+    CK(hipFree(a)); CK(hipFree(b)); CK(hipFree(sink));
+}
+
+// ---- VALU issue cost -----------------------------------------------------------------------------------------------
+// Each kernel: kIters iterations of 8 independent instructions of one kind (8 accumulators: no dependency stalls), bracketed
+// by s_memtime; the host divides the elapsed shader cycles by the wave-instructions one SIMD issued in that window.
+constexpr int kIters = 4096;
+
+#define STREAM8(ASM)                                                                                                   \
+    for (int it = 0; it < kIters; ++it) {                                                                              \
+        asm volatile(ASM(0) "\n" ASM(1) "\n" ASM(2) "\n" ASM(3) "\n" ASM(4) "\n" ASM(5) "\n" ASM(6) "\n" ASM(7)      \
+                     : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])  \
+                     : "v"(x), "v"(y));                                                                                \
+    }
+
+#define A_FMA(k) "v_fma_f32 %" #k ", %8, %9, %" #k
+#define A_MUL(k) "v_mul_f32 %" #k ", %8, %" #k
+#define A_ADD(k) "v_add_f32 %" #k ", %8, %" #k
+#define A_MULLO(k) "v_mul_lo_u32 %" #k ", %8, %" #k
+#define A_MULHI(k) "v_mul_hi_u32 %" #k ", %8, %" #k
+#define A_MUL24(k) "v_mul_i32_i24 %" #k ", %8, %" #k
+#define A_MAD24(k) "v_mad_i32_i24 %" #k ", %8, %9, %" #k
+#define A_ADDU(k) "v_add_u32 %" #k ", %8, %" #k
+#define A_RCP(k) "v_rcp_f32 %" #k ", %" #k
+#define A_SQRT(k) "v_sqrt_f32 %" #k ", %" #k
+#define A_CVT(k) "v_cvt_f32_i32 %" #k ", %" #k
+#define A_CVTU(k) "v_cvt_u32_f32 %" #k ", %" #k
+#define A_FLOOR(k) "v_floor_f32 %" #k ", %" #k
+#define A_FRACT(k) "v_fract_f32 %" #k ", %" #k
+#define A_MOV(k) "v_mov_b32 %" #k ", %8"
+#define A_MED3(k) "v_med3_f32 %" #k ", %" #k ", %8, %9"
+#define A_MAX(k) "v_max_f32 %" #k ", %8, %" #k
+#define A_CMP(k) "v_cmp_lt_f32 vcc, %8, %" #k "\nv_cndmask_b32 %" #k ", %8, %9, vcc"
+#define A_LSHL(k) "v_lshlrev_b32 %" #k ", 1, %" #k
+#define A_AND(k) "v_and_b32 %" #k ", %8, %" #k
+#define A_ADD64(k) "v_add_co_u32 %" #k ", vcc, %8, %" #k "\nv_addc_co_u32 %" #k ", vcc, %9, %" #k ", vcc"
+#define A_PKFMA(k) "v_pk_fma_f32 %" #k ", %8, %9, %" #k
+
+struct Stamp { uint64_t t0, t1; };
+
+#define VALU_KERNEL(NAME, ASM, TYPE)                                                                                   \
+    __global__ __launch_bounds__(256) void NAME(Stamp* __restrict__ st, TYPE x, TYPE y, TYPE* __restrict__ out) {     \
+        TYPE r[8];                                                                                                     \
+        for (int k = 0; k < 8; ++k) r[k] = x + (TYPE)(threadIdx.x + k);                                                \
+        __syncthreads();                                                                                               \
+        const uint64_t t0 = __builtin_amdgcn_s_memtime();                                                              \
+        STREAM8(ASM)                                                                                                   \
+        asm volatile("s_nop 0" ::: "memory");                                                                          \
+        const uint64_t t1 = __builtin_amdgcn_s_memtime();                                                              \
+        TYPE acc = r[0];                                                                                               \
+        for (int k = 1; k < 8; ++k) acc += r[k];                                                                       \
+        if ((threadIdx.x & 63) == 0) st[blockIdx.x * 4 + (threadIdx.x >> 6)] = Stamp{t0, t1};                          \
+        if (acc == (TYPE)12345) out[0] = acc;                                                                          \
+    }
+
+VALU_KERNEL(v_fma, A_FMA, float)
+VALU_KERNEL(v_mul, A_MUL, float)
+VALU_KERNEL(v_add, A_ADD, float)
+VALU_KERNEL(v_mullo, A_MULLO, uint32_t)
+VALU_KERNEL(v_mulhi, A_MULHI, uint32_t)
+VALU_KERNEL(v_mul24, A_MUL24, uint32_t)
+VALU_KERNEL(v_mad24, A_MAD24, uint32_t)
+VALU_KERNEL(v_addu, A_ADDU, uint32_t)
+VALU_KERNEL(v_rcp, A_RCP, float)
+VALU_KERNEL(v_sqrt, A_SQRT, float)
+VALU_KERNEL(v_cvt_f32_i32, A_CVT, float)
+VALU_KERNEL(v_cvt_u32_f32, A_CVTU, float)
+VALU_KERNEL(v_floor, A_FLOOR, float)
+VALU_KERNEL(v_fract, A_FRACT, float)
+VALU_KERNEL(v_mov, A_MOV, float)
+VALU_KERNEL(v_med3, A_MED3, float)
+VALU_KERNEL(v_max, A_MAX, float)
+VALU_KERNEL(v_cmp_cndmask, A_CMP, float)
+VALU_KERNEL(v_lshl, A_LSHL, uint32_t)
+VALU_KERNEL(v_and, A_AND, uint32_t)
+VALU_KERNEL(v_add64, A_ADD64, uint32_t)
+
+template <typename K, typename T>
+static void time_valu(const char* name, K kernel, T x, T y, int insts_per_slot, std::string& json) {
+    int cus = 0;
+    CK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0));
+    Stamp* st = nullptr;
+    T* out = nullptr;
+    CK(hipMalloc((void**)&out, 64));
+    double res[2] = {0, 0};
+    const int occ[2] = {1, 8};
+    for (int o = 0; o < 2; ++o) {
+        const int wgs = cus * occ[o];           // 4 waves per workgroup = one per SIMD; occ[o] workgroups per CU
+        CK(hipMalloc((void**)&st, sizeof(Stamp) * wgs * 4));
+        for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL(kernel, dim3(wgs), dim3(256), 0, 0, st, x, y, out);
+        CK(hipDeviceSynchronize());
+        std::vector<Stamp> h(wgs * 4);
+        CK(hipMemcpy(h.data(), st, sizeof(Stamp) * wgs * 4, hipMemcpyDeviceToHost));
+        // median elapsed cycles of a wave; under full occupancy all occ[o] waves of a SIMD run for that whole window
+        std::vector<double> el;
+        for (auto& s : h) el.push_back((double)(s.t1 - s.t0));
+        std::sort(el.begin(), el.end());
+        const double med = el[el.size() / 2];
+        res[o] = med / ((double)kIters * 8 * insts_per_slot * occ[o]);
+        CK(hipFree(st));
+    }
+    char buf[256];
+    snprintf(buf, sizeof buf, "%s\"%s\": {\"cyc_per_inst_1wave\": %.3f, \"cyc_per_inst_8waves\": %.3f}", json.empty() ? "" : ", ", name, res[0], res[1]);
+    json += buf;
+    CK(hipFree(out));
+}
+
+#include <algorithm>
+
+static void run_valu() {
+    std::string j;
+    time_valu("v_fma_f32", v_fma, 1.0001f, 0.5f, 1, j);
+    time_valu("v_mul_f32", v_mul, 1.0001f, 0.5f, 1, j);
+    time_valu("v_add_f32", v_add, 1.0001f, 0.5f, 1, j);
+    time_valu("v_mul_lo_u32", v_mullo, 3u, 5u, 1, j);
+    time_valu("v_mul_hi_u32", v_mulhi, 3u, 5u, 1, j);
+    time_valu("v_mul_i32_i24", v_mul24, 3u, 5u, 1, j);
+    time_valu("v_mad_i32_i24", v_mad24, 3u, 5u, 1, j);
+    time_valu("v_add_u32", v_addu, 3u, 5u, 1, j);
+    time_valu("v_rcp_f32", v_rcp, 1.5f, 0.5f, 1, j);
+    time_valu("v_sqrt_f32", v_sqrt, 1.5f, 0.5f, 1, j);
+    time_valu("v_cvt_f32_i32", v_cvt_f32_i32, 1.5f, 0.5f, 1, j);
+    time_valu("v_cvt_u32_f32", v_cvt_u32_f32, 1.5f, 0.5f, 1, j);
+    time_valu("v_floor_f32", v_floor, 1.5f, 0.5f, 1, j);
+    time_valu("v_fract_f32", v_fract, 1.5f, 0.5f, 1, j);
+    time_valu("v_mov_b32", v_mov, 1.5f, 0.5f, 1, j);
+    time_valu("v_med3_f32", v_med3, 1.5f, 0.5f, 1, j);
+    time_valu("v_max_f32", v_max, 1.5f, 0.5f, 1, j);
+    time_valu("v_cmp+v_cndmask", v_cmp_cndmask, 1.5f, 0.5f, 2, j);
+    time_valu("v_lshlrev_b32", v_lshl, 3u, 5u, 1, j);
+    time_valu("v_and_b32", v_and, 3u, 5u, 1, j);
+    time_valu("v_add_co+v_addc (64-bit add)", v_add64, 3u, 5u, 2, j);
+    int clk = 0;
+    CK(hipDeviceGetAttribute(&clk, hipDeviceAttributeClockRate, 0));
+    printf("{\"valu_issue_cost\": {%s}, \"unit\": \"shader cycles (s_memtime) per wave64 instruction per SIMD\", \"clock_rate_khz\": %d}\n", j.c_str(), clk);
+}
+
+int main(int argc, char** argv) {
+    if (argc > 1 && !strcmp(argv[1], "hbm")) run_hbm();
+    else if (argc > 1 && !strcmp(argv[1], "valu")) run_valu();
+    else { fprintf(stderr, "usage: calib hbm|valu\n"); return 2; }
+    return 0;
+}

@@ -190,7 +190,7 @@ int TerrainRenderer::add_terrain(int32_t lat, int32_t lon, const float* heights,
     hipError_t e = hipMalloc((void**)&t.d_normals, texels * 4);
     // one allocation: block min/max (2 floats per block), then the sin/cos tables of the w columns and the h rows
     const size_t tile_floats = (size_t)bxc * byc * 2 + 2 * ((size_t)w + h);   // even: the f64 block bounds that follow stay 8-byte aligned
-    if (e == hipSuccess) e = hipMalloc((void**)&t.d_minmax, tile_floats * sizeof(float) + (size_t)bxc * byc * 16 * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&t.d_minmax, tile_floats * sizeof(float) + (size_t)bxc * byc * 17 * sizeof(double));   // sphere 4 + corners 12 + sagitta 1
     if (e == hipSuccess) e = hipMemcpyAsync(t.d_heights, heights, texels * 4, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream_);
     // (the zero-initialised normal texture: k_normals_interior writes the untouched border ring as zero)
     if (e != hipSuccess) {

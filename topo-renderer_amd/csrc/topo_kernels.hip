@@ -130,9 +130,21 @@ __global__ __launch_bounds__(64) void k_block_minmax(TileDev t, uint32_t w, uint
             const double d2 = dx * dx + dy * dy + dz * dz;
             r2 = d2 > r2 ? d2 : r2;
         }
-        // corners bound the patch up to its sagitta (< 1 m for a 6 km block); + half the height range + margin
+        // every direction of the patch lies within the angular distance of the farthest corner from the centre direction,
+        // so the corners' chord distance bounds the sphere; + half the height range + margin
         bs[0] = c[0]; bs[1] = c[1]; bs[2] = c[2];
         bs[3] = sqrt(r2) + 0.5 * (hmax - hmin) + 8.0 + 64.0;
+        // How far the curved patch can stick out of the flat-faced hull of its eight slab corners (radially over the top
+        // face, sideways over the face along its equator-side parallel): at most the sagitta of the farthest corner's
+        // arc, R (1 - cos theta_max).  0.3 .. 0.7 m for a 60 x 15 cell block of a 1200-px tile, hundreds of metres for the
+        // blocks of a coarse tile: the occlusion filter pads its slab by this and only takes blocks where it is <= 1 m.
+        double dmin = 1.0;
+        const double uc[3] = {lac.c * loc.c, lac.c * loc.s, lac.s};
+        for (int k = 0; k < 4; ++k) {
+            const double d = u[k][0] * uc[0] + u[k][1] * uc[1] + u[k][2] * uc[2];
+            dmin = d < dmin ? d : dmin;
+        }
+        const_cast<double*>(t.block_bounds)[(size_t)gridDim.x * 16 + blk] = ((double)kR0 + (hmax > 0.0 ? hmax : 0.0) + 2.0) * (1.0 - dmin);
     }
     for (uint32_t e = blk * 64 + threadIdx.x; e < w + h; e += gridDim.x * 64) {
         float sn, cs;
@@ -299,8 +311,10 @@ __device__ __forceinline__ void clip_plane(const float* m, int pl, double out[5]
 //    six clip planes of camera_proj -- culled blocks cannot produce fragments;
 //  * near/far split: blocks whose nearest possible view depth exceeds P.split_m become occlusion-test candidates
 //    (FarItem) instead of work items; for them the lane also projects the eight corners of the block's bounding
-//    slab -- the lat/lon rectangle of its vertices x [hmin - 1 m, hmax + 2 m], which contains every triangle of the
-//    block up to < 1 m of chord sagitta -- and records the pixel box (+-2 px) and a lower bound of the depths
+//    slab -- the lat/lon rectangle of its vertices x [hmin - 1 m, hmax + 2 m + sagitta]: the flat-faced hull of those
+//    eight points contains every triangle of the block (k_block_minmax measures the sagitta; blocks where it exceeds
+//    1 m -- coarse tiles -- are never candidates) -- and records the pixel box (+-2 px; a sideways bulge of <= 1 m is
+//    < 0.001 px beyond the split distance) and a lower bound of the depths
 //    (z_ndc at the smallest corner w, minus 8/w: the f32 clip-space cancellation noise is ~1 clip unit).
 // Emit a block the raster must visit.  With the occlusion filter on, such blocks are few and heavy (large triangles),
 // so each is cut into strips of kStrip cell rows to spread them over the resident waves:
@@ -358,7 +372,9 @@ __global__ __launch_bounds__(256) void k_cull(FrameParams P) {
             // view depth of the nearest point the block can contain
             const double wn = sqrt((double)m[3] * m[3] + (double)m[7] * m[7] + (double)m[11] * m[11]);
             const double w_near = ((double)m[3] * c[0] + (double)m[7] * c[1] + (double)m[11] * c[2] + (double)m[15]) - radius * wn;
-            if (sane && P.split_m > 0.0f && w_near > (double)P.split_m) {
+            // (coarse tiles: a block whose curvature exceeds the slab's 1 m allowance is always rastered, never filtered)
+            const double sagitta = t.block_bounds[(size_t)blocks_per_tile * 16 + blk];
+            if (sane && P.split_m > 0.0f && w_near > (double)P.split_m && sagitta <= 1.0) {
                 const uint32_t fslot = atomicAdd(&s_nfar, 1u);
                 if (TOPO_CHK(P.counters, fslot < 256u, 5u, fslot)) s_far[fslot] = threadIdx.x;
             }
@@ -378,7 +394,7 @@ __global__ __launch_bounds__(256) void k_cull(FrameParams P) {
         const double* bb = t.block_bounds + (size_t)blocks_per_tile * 4 + (size_t)blk * 12;   // corner directions
         const float* m = P.views[view].proj;
         double bxlo = 1e30, bxhi = -1e30, bylo = 1e30, byhi = -1e30, wmin = 1e30, zclip_at_wmin = 0.0;
-        const double hs[2] = {hmin - 1.0, hmax + 2.0};
+        const double hs[2] = {hmin - 1.0, hmax + 2.0 + t.block_bounds[(size_t)blocks_per_tile * 16 + blk]};      // + the patch's sagitta (<= 1 m here)
         for (int k = 0; k < 8; ++k) {
             const double R = (double)kR0 + hs[k >> 2];
             const double px = R * bb[3 * (k & 3)], py = R * bb[3 * (k & 3) + 1], pz = R * bb[3 * (k & 3) + 2];

@@ -18,7 +18,8 @@ struct TileDev {                 // one loaded 1x1 degree tile (RenderBuffer, re
     const float* trig_lon;       // w (sin, cos) pairs: sincos_f(vertex_lon(t, x)) of every vertex column ...
     const float* trig_lat;       // h pairs: sincos_f(vertex_lat(t, y)) of every vertex row (load phase, k_block_minmax)
     const double* block_bounds;  // for the cull, view-independent (k_block_minmax): 4 doubles per raster block (bounding-sphere
-                                 // centre and radius), then 12 per block (unit directions of its four corners)
+                                 // centre and radius), then 12 per block (unit directions of its four corners), then 1 per
+                                 // block (sagitta of the patch over the flat hull of its corners, metres)
     float raster_x, raster_y;    // TerrainUniforms (render/data.rs:113-121)
     float model_x, model_y;
     float scale_x, scale_y;
