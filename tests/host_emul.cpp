@@ -98,6 +98,9 @@ static void emul_emit(const TriSetup& ts, uint64_t* vis, int W, uint32_t id) {
     }
 }
 
+static int g_split = 0;
+void emul_set_split(int on) { g_split = on; }
+
 // tiles must be given in draw (BTreeMap) order
 int emul_render(const EmulTile* tiles, uint32_t n_tiles, uint32_t tile_w, uint32_t tile_h, const float* uniforms40,
                 int W, int H, uint8_t* rgba, float* depth) {
@@ -167,8 +170,12 @@ int emul_render(const EmulTile* tiles, uint32_t n_tiles, uint32_t tile_w, uint32
         float lin[4] = {0.0f, 0.71f, 0.885f, 1.0f};
         if (id != kNoTri) {
             const uint32_t draw = id >> 1, fan = id & 1u, rank = fastdiv(draw, div_tris), tri = draw - rank * tris_per_tile;
-            f3 wpos, wnrm;
-            if (!resolve_varyings(td[rank], tile_w, div_hm1, tile_h - 1, view, W, H, tri, fan, ndec, px, py, wpos, wnrm)) return -1;
+            f3 wpos = {0.0f, 0.0f, 0.0f}, wnrm;
+            if (g_split) {      // the two-step route k_resolve takes for waves whose pixels share few winners
+                TriRecord rec;
+                resolve_setup(td[rank], tile_w, div_hm1, tile_h - 1, view, W, H, tri, fan, ndec, rec);
+                if (!resolve_pixel(rec, W, H, px, py, wpos.x, wpos.y, wnrm)) return -1;
+            } else if (!resolve_varyings(td[rank], tile_w, div_hm1, tile_h - 1, view, W, H, tri, fan, ndec, px, py, wpos, wnrm)) return -1;
             shade_fragment(view.view_mode, {view.sun[0], view.sun[1], view.sun[2]}, view.cam_x, view.cam_y, (float)px + 0.5f,
                            (float)py + 0.5f, wpos, wnrm, lin);
         }

@@ -304,3 +304,27 @@ def test_raster_rows_stays_in_bounds_and_matches_triangle_pixel():
         assert ng.value == nr.value and np.array_equal(got, ref), f"triangle {i}"
         walked += ng.value > 0
     assert walked > 100
+
+
+def test_split_resolve_equals_resolve_varyings(topo, orc):
+    """resolve_setup + resolve_pixel (per-triangle record, then per pixel: the route k_resolve takes for waves whose pixels
+    share few winners) gives the frame resolve_varyings gives, and both equal the oracle's -- uncut triangles of both
+    barycentric widths, primitives cut by the near plane, every view mode."""
+    L = emul.lib()
+    try:
+        for cfg in CASES + [(12, 2, 2, 200, 150, 10, 35, 110, 0, 60), (12, 2, 2, 160, 120, 200, 80, 110, 2, 60), (24, 1, 1, 96, 96, 33, 89, 140, 0, 3)]:
+            tile, n_lat, n_lon, W, H, yaw, pitch, fov, mode, dh = cfg
+            sc = Scene(tile, n_lat, n_lon, eye_dh=dh)
+            e, o = emul.EmulRenderer(W, H, topo.terrain_uniforms), orc.OracleRenderer(W, H)
+            sc.load(e)
+            sc.load(o)
+            u, pu = sc.uniforms(W, H, yaw, pitch, fov, mode), topo.post_uniforms(W, H)
+            e.update(W, H, u, pu)
+            o.update(W, H, u, pu)
+            ref = o.render()
+            L.emul_set_split(1)
+            assert_same_frame(e.render(), ref, f"split route {cfg}")
+            L.emul_set_split(0)
+            assert_same_frame(e.render(), ref, f"one-step route {cfg}")
+    finally:
+        L.emul_set_split(0)

@@ -171,13 +171,22 @@ static void time_valu(const char* name, K kernel, T x, T y, int insts_per_slot, 
     Stamp* st = nullptr;
     T* out = nullptr;
     CK(hipMalloc((void**)&out, 64));
-    double res[2] = {0, 0};
+    double res[2] = {0, 0}, ns[2] = {0, 0}, span[2] = {0, 0}, wall[2] = {0, 0};
     const int occ[2] = {1, 8};
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
     for (int o = 0; o < 2; ++o) {
         const int wgs = cus * occ[o];           // 4 waves per workgroup = one per SIMD; occ[o] workgroups per CU
         CK(hipMalloc((void**)&st, sizeof(Stamp) * wgs * 4));
-        for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL(kernel, dim3(wgs), dim3(256), 0, 0, st, x, y, out);
+        hipLaunchKernelGGL(kernel, dim3(wgs), dim3(256), 0, 0, st, x, y, out);
+        CK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(kernel, dim3(wgs), dim3(256), 0, 0, st, x, y, out);
+        CK(hipEventRecord(e1, 0));
         CK(hipDeviceSynchronize());
+        float ms = 0.0f;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        ns[o] = (double)ms * 1e6 / ((double)kIters * 8 * insts_per_slot * occ[o]);      // wall time per wave-instruction of one SIMD
         std::vector<Stamp> h(wgs * 4);
         CK(hipMemcpy(h.data(), st, sizeof(Stamp) * wgs * 4, hipMemcpyDeviceToHost));
         // median elapsed cycles of a wave; under full occupancy all occ[o] waves of a SIMD run for that whole window
@@ -185,11 +194,16 @@ static void time_valu(const char* name, K kernel, T x, T y, int insts_per_slot, 
         for (auto& s : h) el.push_back((double)(s.t1 - s.t0));
         std::sort(el.begin(), el.end());
         const double med = el[el.size() / 2];
+        uint64_t tmin = ~0ull, tmax = 0;
+        for (auto& s : h) { tmin = s.t0 < tmin ? s.t0 : tmin; tmax = s.t1 > tmax ? s.t1 : tmax; }
+        span[o] = (double)(tmax - tmin);       // ticks from the first wave's start to the last wave's end
+        wall[o] = (double)ms * 1e6;
         res[o] = med / ((double)kIters * 8 * insts_per_slot * occ[o]);
         CK(hipFree(st));
     }
-    char buf[256];
-    snprintf(buf, sizeof buf, "%s\"%s\": {\"cyc_per_inst_1wave\": %.3f, \"cyc_per_inst_8waves\": %.3f}", json.empty() ? "" : ", ", name, res[0], res[1]);
+    char buf[512];
+    snprintf(buf, sizeof buf, "%s\"%s\": {\"cyc_per_inst_1wave\": %.3f, \"cyc_per_inst_8waves\": %.3f, \"ns_per_inst_1wave\": %.4f, \"ns_per_inst_8waves\": %.4f, \"ticks_per_ns_8waves\": %.4f, \"wave_window_over_kernel_span_8waves\": %.3f}",
+             json.empty() ? "" : ", ", name, res[0], res[1], ns[0], ns[1], span[1] / wall[1], res[1] * kIters * 8 * insts_per_slot * 8 / span[1]);
     json += buf;
     CK(hipFree(out));
 }
@@ -221,7 +235,7 @@ static void run_valu() {
     time_valu("v_add_co+v_addc (64-bit add)", v_add64, 3u, 5u, 2, j);
     int clk = 0;
     CK(hipDeviceGetAttribute(&clk, hipDeviceAttributeClockRate, 0));
-    printf("{\"valu_issue_cost\": {%s}, \"unit\": \"shader cycles (s_memtime) per wave64 instruction per SIMD\", \"clock_rate_khz\": %d}\n", j.c_str(), clk);
+    printf("{\"valu_issue_cost\": {%s}, \"unit\": \"cyc_*: s_memtime ticks, ns_*: HIP-event wall time (incl. ~10 us of launch), per wave64 instruction per SIMD\", \"clock_rate_khz\": %d}\n", j.c_str(), clk);
 }
 
 int main(int argc, char** argv) {

@@ -830,30 +830,39 @@ __global__ __launch_bounds__(256) void k_raster_big(FrameParams P) {
 }
 
 // ---- resolve: fs_main for the winner of every pixel, then the post pass --------------------------------
-// One workgroup shades a 64 x kResolveRows px block, wave w taking rows w, w + 4, ...  The block's visibility keys
-// (+ 1 px halo for the contour taps, clamp-to-edge) are read from memory exactly once, into LDS: linear depth with
-// halo, raw depth and triangle id for the block's own pixels.  A block that holds no terrain at all (about half of a
-// panorama is sky) is written out as constants without any per-pixel work: with every tap at depth 1 the contour
-// term is exactly 0 (8c - 8 times c in integers) and the post pass returns the cleared texel unchanged.
-#ifndef TOPO_RESOLVE_ROWS
-#define TOPO_RESOLVE_ROWS 16
-#endif
+// One workgroup shades a 64 x 16 px block, wave w taking rows w, w + 4, w + 8, w + 12 (interleaved: the terrain/sky
+// boundary is mostly horizontal, so the four waves of a block get similar work).  Every lane reads the visibility keys
+// of its own four pixels straight into registers (512-byte row segments); the linear depths the contour taps need go to
+// LDS -- the block's own by their owners, the 1 px halo ring (clamp-to-edge) by the first 164 threads.  A block that
+// holds no terrain at all (about half of a panorama is sky) is written out as constants without any per-pixel work:
+// with every tap at depth 1 the contour term is exactly 0 and the post pass returns the cleared texel unchanged.
+//
+// Winners are shared: the near field consists of triangles tens to thousands of pixels large, and two thirds of a
+// pixel's arithmetic (three vs_main, the perspective divides, the doubled area: resolve_setup) depends on the winning
+// triangle alone.  Each wave therefore lists the distinct winners of its 256 pixels -- a lane starts a new entry when
+// its id differs from its left neighbour's -- and, if they are at most 64, computes their records densely, one triangle
+// per lane, into a per-wave LDS table; the pixels then finish from the record (resolve_pixel: the same operations on the
+// same values, bit for bit).  A wave that meets more than 64 distinct winners (far field: a triangle or less per pixel)
+// shades each pixel on its own (resolve_varyings) as round 1 did for every pixel.
+constexpr int kResolveRows = 16;
+constexpr uint32_t kRecCap = 64;       // triangle records per wave
 #ifndef TOPO_RESOLVE_WGS
-#define TOPO_RESOLVE_WGS 6
+#define TOPO_RESOLVE_WGS 4
 #endif
-constexpr int kResolveRows = TOPO_RESOLVE_ROWS;
 __global__ __launch_bounds__(256, TOPO_RESOLVE_WGS) void k_resolve(FrameParams P, OutputParams O) {
     __shared__ float s_thresh[258];    // sRGB code boundaries; [255..257] = NaN: never <= anything (srgb_encode_lut probes up to 256)
     __shared__ float s_decode[256];
     __shared__ float s_ndec[256];      // normal channel decode 2c/255 - 1
     __shared__ uint32_t s_lut[1024];   // 4096 one-byte bins of srgb_encode_lut
-    __shared__ float s_lin[kResolveRows + 2][66];   // linear depth of the block + halo
-    __shared__ uint32_t s_raw[kResolveRows][64];    // depth bits of the block's pixels
-    __shared__ uint32_t s_id[kResolveRows][64];     // winner ids
-    __shared__ uint32_t s_any[4];                   // per wave: did its part of the block + halo hold terrain
+    __shared__ float s_lin[kResolveRows + 2][66];            // linear depth of the block + halo
+    __shared__ uint32_t s_rec[4][kTriRecordWords][kRecCap];  // per wave: the records, word-major (lanes with consecutive slots hit consecutive banks)
+    __shared__ uint32_t s_uid[4][kRecCap];                   // per wave: the distinct winner ids
+    __shared__ uint32_t s_any[4];                            // per wave: did its part of the block + halo hold terrain
     const uint32_t view_idx = blockIdx.z;
     const uint64_t* vis = P.vis + (size_t)view_idx * P.W * P.H;
     const int32_t bx = blockIdx.x * 64, by = blockIdx.y * kResolveRows;
+    const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int32_t tx = (int32_t)lane, px = bx + tx;
     // every row of the block + halo spans at most three 64-key segments: if none of them is marked, nothing was drawn here
     bool terrain = false;
     if (threadIdx.x < (kResolveRows + 2) * 3) {
@@ -865,34 +874,43 @@ __global__ __launch_bounds__(256, TOPO_RESOLVE_WGS) void k_resolve(FrameParams P
         const size_t seg = ((first + x0) >> 6) + k;
         terrain = seg <= ((first + x1) >> 6) && TOPO_CHK(P.counters, seg < (((size_t)P.n_views * P.W * P.H + 63) >> 6), 12u, seg) && P.dirty[seg] != 0;
     }
+    uint8_t* const rgba_col = O.rgba + (size_t)view_idx * O.rgba_view_stride + (size_t)px * 4;
+    uint8_t* const depth_col = O.depth ? reinterpret_cast<uint8_t*>(O.depth) + (size_t)view_idx * O.depth_view_stride + (size_t)px * 4 : nullptr;
     if (__syncthreads_or(terrain) == 0) {        // workgroup-uniform: write the cleared texel and depth 1
-        const int32_t px = bx + (int32_t)(threadIdx.x & 63);
         if (px >= P.W) return;
-        for (int32_t ty = threadIdx.x >> 6; ty < kResolveRows && by + ty < P.H; ty += 4) {
-            *reinterpret_cast<uint32_t*>(O.rgba + (size_t)view_idx * O.rgba_view_stride + (size_t)(by + ty) * O.rgba_pitch + (size_t)px * 4) = P.sky_c8;
-            if (O.depth)
-                *reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(O.depth) + (size_t)view_idx * O.depth_view_stride +
-                                          (size_t)(by + ty) * O.depth_pitch + (size_t)px * 4) = 1.0f;
+        for (int32_t ty = (int32_t)wave; ty < kResolveRows && by + ty < P.H; ty += 4) {
+            *reinterpret_cast<uint32_t*>(rgba_col + (size_t)(by + ty) * O.rgba_pitch) = P.sky_c8;
+            if (depth_col) *reinterpret_cast<float*>(depth_col + (size_t)(by + ty) * O.depth_pitch) = 1.0f;
         }
         return;
     }
+    // ---- keys: own pixels into registers (+ their linear depth into LDS), halo ring into LDS
+    uint32_t ids[4], raws[4];
     terrain = false;
-    for (int idx = threadIdx.x; idx < (kResolveRows + 2) * 66; idx += 256) {
-        const int ly = idx / 66, lx = idx - ly * 66;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int32_t ty = (int32_t)wave + 4 * r, py = by + ty;
+        // (outside the target the tap positions clamp to the edge; those lanes / rows only feed the LDS tile)
+        const int32_t cx = px > P.W - 1 ? P.W - 1 : px, cy = py > P.H - 1 ? P.H - 1 : py;
+        const uint64_t key = vis[(size_t)cy * P.W + cx];
+        ids[r] = (uint32_t)key;
+        raws[r] = (uint32_t)(key >> 32);
+        terrain |= raws[r] != 0x3F800000u;
+        s_lin[ty + 1][tx + 1] = linear_depth(bits_f(raws[r]));
+    }
+    if (threadIdx.x < 2 * 66 + 2 * kResolveRows) {      // the ring: rows -1 and 16 (66 entries each), columns -1 and 64 of rows 0..15
+        int32_t ly, lx;
+        if (threadIdx.x < 132) { ly = threadIdx.x < 66 ? 0 : kResolveRows + 1; lx = (int32_t)threadIdx.x % 66; }
+        else { const int32_t k = (int32_t)threadIdx.x - 132; ly = 1 + (k >> 1); lx = (k & 1) ? 65 : 0; }
         int32_t x = bx + lx - 1, y = by + ly - 1;
         x = x < 0 ? 0 : (x > P.W - 1 ? P.W - 1 : x);   // clamp-to-edge depth sampler (texture.rs:113-117)
         y = y < 0 ? 0 : (y > P.H - 1 ? P.H - 1 : y);
-        const uint64_t key = vis[(size_t)y * P.W + x];
-        const uint32_t hi = (uint32_t)(key >> 32);
+        const uint32_t hi = (uint32_t)(vis[(size_t)y * P.W + x] >> 32);
         terrain |= hi != 0x3F800000u;
         s_lin[ly][lx] = linear_depth(bits_f(hi));
-        if (lx >= 1 && lx <= 64 && ly >= 1 && ly <= kResolveRows) {
-            s_raw[ly - 1][lx - 1] = hi;
-            s_id[ly - 1][lx - 1] = (uint32_t)key;
-        }
     }
     const uint64_t any_mask = __ballot(terrain);
-    if ((threadIdx.x & 63) == 0) s_any[threadIdx.x >> 6] = any_mask != 0 ? 1u : 0u;
+    if (lane == 0) s_any[wave] = any_mask != 0 ? 1u : 0u;
     s_thresh[threadIdx.x] = threadIdx.x < 255 ? bits_f(TOPO_SRGB_THRESH_BITS[threadIdx.x]) : NAN;
     if (threadIdx.x < 2) s_thresh[256 + threadIdx.x] = NAN;
     s_decode[threadIdx.x] = bits_f(TOPO_SRGB_DECODE_BITS[threadIdx.x]);
@@ -900,12 +918,10 @@ __global__ __launch_bounds__(256, TOPO_RESOLVE_WGS) void k_resolve(FrameParams P
 #pragma unroll
     for (int k = 0; k < 4; ++k) s_lut[threadIdx.x + 256 * k] = TOPO_SRGB_LUT12_WORDS[threadIdx.x + 256 * k];
     __syncthreads();
-    const int32_t tx = threadIdx.x & 63, px = bx + tx;
-    if (px >= P.W) return;
-    uint8_t* const rgba_col = O.rgba + (size_t)view_idx * O.rgba_view_stride + (size_t)px * 4;
-    uint8_t* const depth_col = O.depth ? reinterpret_cast<uint8_t*>(O.depth) + (size_t)view_idx * O.depth_view_stride + (size_t)px * 4 : nullptr;
+    const bool in_x = px < P.W;        // lanes beyond the target's right edge stay: they compute triangle records below
     if ((s_any[0] | s_any[1] | s_any[2] | s_any[3]) == 0) {      // workgroup-uniform
-        for (int32_t ty = threadIdx.x >> 6; ty < kResolveRows && by + ty < P.H; ty += 4) {
+        if (!in_x) return;
+        for (int32_t ty = (int32_t)wave; ty < kResolveRows && by + ty < P.H; ty += 4) {
             *reinterpret_cast<uint32_t*>(rgba_col + (size_t)(by + ty) * O.rgba_pitch) = P.sky_c8;
             if (depth_col) *reinterpret_cast<float*>(depth_col + (size_t)(by + ty) * O.depth_pitch) = 1.0f;
         }
@@ -913,20 +929,60 @@ __global__ __launch_bounds__(256, TOPO_RESOLVE_WGS) void k_resolve(FrameParams P
     }
     const uint8_t* lut = reinterpret_cast<const uint8_t*>(s_lut);
     const ViewDev& view = P.views[view_idx];
+
+    // ---- the distinct winners of this wave's pixels: a lane opens an entry where its id differs from its left neighbour's
+    uint32_t slot[4];
+    uint32_t n_uniq = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const bool valid = in_x && by + (int32_t)wave + 4 * r < P.H && ids[r] != kNoTri;
+        const uint32_t left = (uint32_t)__shfl_up((int)ids[r], 1);
+        const bool leader = valid && (lane == 0 || ids[r] != left);
+        const uint64_t mask = __ballot(leader);
+        const uint32_t upto = (uint32_t)__popcll(mask & ((2ull << lane) - 1ull));      // leaders at or before this lane
+        slot[r] = n_uniq + upto - 1u;      // meaningful for valid lanes: their run's leader is the last leader at or before them
+        if (leader && slot[r] < kRecCap) s_uid[wave][slot[r]] = ids[r];
+        n_uniq += (uint32_t)__popcll(mask);
+    }
+    const bool shared = n_uniq <= kRecCap;      // wave-uniform
+    if (shared && lane < n_uniq) {
+        const uint32_t id = s_uid[wave][lane];
+        const uint32_t draw = id >> 1, fan = id & 1u;
+        const uint32_t rank = fastdiv(draw, P.div_tris), tri = draw - rank * P.tris_per_tile;
+        TriRecord rec;
+        if (TOPO_CHK(P.counters, rank < P.n_tiles, 13u, id)) resolve_setup(P.tiles[rank], P.tile_w, P.div_hm1, P.tile_h - 1, view, P.W, P.H, tri, fan, s_ndec, rec);
+        else rec.kind = 0;
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(&rec);
+#pragma unroll
+        for (int k = 0; k < kTriRecordWords; ++k) s_rec[wave][k][lane] = w[k];
+    }
+    // (the table is read only by the wave that wrote it: LDS operations of one wave complete in order)
+
 #pragma unroll 1
-    for (int32_t ty = threadIdx.x >> 6; ty < kResolveRows; ty += 4) {
-        const int32_t py = by + ty;
+    for (int r = 0; r < 4; ++r) {
+        const int32_t ty = (int32_t)wave + 4 * r, py = by + ty;
         if (py >= P.H) break;
-        const uint32_t id = s_id[ty][tx];
+        const uint32_t id = in_x ? ids[r] : kNoTri;
         // render target texel (Rgba8UnormSrgb): the cleared value or the shaded winner
         uint32_t c8 = P.sky_c8;
         if (id != kNoTri) {
             float lin[4] = {0.0f, 0.71f, 0.885f, 1.0f};
-            const uint32_t draw = id >> 1, fan = id & 1u;
-            const uint32_t rank = fastdiv(draw, P.div_tris), tri = draw - rank * P.tris_per_tile;
-            f3 wpos, wnrm;
-            if (TOPO_CHK(P.counters, rank < P.n_tiles, 13u, id) &&
-                resolve_varyings(P.tiles[rank], P.tile_w, P.div_hm1, P.tile_h - 1, view, P.W, P.H, tri, fan, s_ndec, px, py, wpos, wnrm)) {
+            f3 wpos = {0.0f, 0.0f, 0.0f}, wnrm;
+            bool ok;
+            if (shared) {
+                TriRecord rec;
+                uint32_t* w = reinterpret_cast<uint32_t*>(&rec);
+                const uint32_t sl = slot[r];
+#pragma unroll
+                for (int k = 0; k < kTriRecordWords; ++k) w[k] = s_rec[wave][k][sl];
+                ok = resolve_pixel(rec, P.W, P.H, px, py, wpos.x, wpos.y, wnrm);
+            } else {
+                const uint32_t draw = id >> 1, fan = id & 1u;
+                const uint32_t rank = fastdiv(draw, P.div_tris), tri = draw - rank * P.tris_per_tile;
+                ok = TOPO_CHK(P.counters, rank < P.n_tiles, 13u, id) &&
+                     resolve_varyings(P.tiles[rank], P.tile_w, P.div_hm1, P.tile_h - 1, view, P.W, P.H, tri, fan, s_ndec, px, py, wpos, wnrm);
+            }
+            if (ok) {
                 const f3 sun = {view.sun[0], view.sun[1], view.sun[2]};
                 shade_fragment(view.view_mode, sun, view.cam_x, view.cam_y, (float)px + 0.5f, (float)py + 0.5f, wpos, wnrm, lin);
             }
@@ -943,8 +999,10 @@ __global__ __launch_bounds__(256, TOPO_RESOLVE_WGS) void k_resolve(FrameParams P
                 ln[k++] = s_lin[ty + 1 + j][tx + 1 + i];
             }
         const uint32_t out = post_pixel_t<true>(s_thresh, s_decode, c8, s_lin[ty + 1][tx + 1], ln, lut);
-        *reinterpret_cast<uint32_t*>(rgba_col + (size_t)py * O.rgba_pitch) = out;
-        if (depth_col) *reinterpret_cast<uint32_t*>(depth_col + (size_t)py * O.depth_pitch) = s_raw[ty][tx];
+        if (in_x) {
+            *reinterpret_cast<uint32_t*>(rgba_col + (size_t)py * O.rgba_pitch) = out;
+            if (depth_col) *reinterpret_cast<uint32_t*>(depth_col + (size_t)py * O.depth_pitch) = raws[r];
+        }
     }
 }
 

@@ -601,6 +601,95 @@ TOPO_HD bool resolve_varyings(const TileDev& t, uint32_t tile_w, FastDiv div_hm1
     return true;
 }
 
+// ---- the same varyings in two steps: once per winning triangle, then per pixel ---------------------------------------
+// Many pixels share a winner (the near field is made of triangles hundreds of pixels large), and two thirds of
+// resolve_varyings -- three vs_main, the perspective divides, the doubled area -- depend on the triangle alone.
+// resolve_setup() computes that part into a 26-word record; resolve_pixel() finishes a pixel from the record with the
+// SAME operations on the same values as resolve_varyings (so the two routes agree bit for bit:
+// tests/test_emul_cpu.py::test_split_resolve_equals_resolve_varyings, and k_resolve uses either route per wave).
+struct TriRecord {
+    // kind 1 / 2 (uncut, int32 / int64 barycentrics): X,Y = snapped vertices, rw = 1 / w_k, iA = 1 / |doubled area|
+    // kind 3 (primitive cut by the near plane): c[k] = (clip.x, clip.y, clip.w) of vertex k  (homogeneous_weights)
+    // kind 0: no varyings (cannot happen for an id that won a pixel; the pixel then keeps the cleared colour)
+    union {
+        struct { int32_t X[3], Y[3]; float rw[3]; float iA; } scr;
+        struct { float c[3][3]; float pad_; } cut;
+    };
+    float wx[3], wy[3];       // world position x, y of the three vertices (fs_main reads world_pos.xy only)
+    f3 n[3];                  // world normals
+    uint32_t kind;
+};
+constexpr int kTriRecordWords = 26;
+static_assert(sizeof(TriRecord) == kTriRecordWords * 4, "TriRecord is stored word by word");
+
+TOPO_HD void resolve_setup(const TileDev& t, uint32_t tile_w, FastDiv div_hm1, uint32_t hm1, const ViewDev& view, int32_t W, int32_t H,
+                           uint32_t tri, uint32_t fan, const float* ndec, TriRecord& rec) {
+    ResolvedTri r;
+    bool cut = false;
+    rec.kind = 0;
+    if (resolve_vertices<true>(t, tile_w, div_hm1, hm1, view, W, H, tri, fan, ndec, r, &cut)) {
+        if (fan == 0) {
+            const int32_t X0 = r.s[0].X, Y0 = r.s[0].Y, X1 = r.s[1].X, Y1 = r.s[1].Y, X2 = r.s[2].X, Y2 = r.s[2].Y;
+            float iA = 0.0f;
+            if (spans_fit_int32(X0, Y0, X1, Y1, X2, Y2)) {
+                const int32_t area2 = TOPO_MUL24(X1 - X0, Y2 - Y0) - TOPO_MUL24(Y1 - Y0, X2 - X0);
+                if (area2 < 0) { iA = div_f(1.0f, (float)(-area2)); rec.kind = 1; }
+            } else {
+                const int64_t area2 = (int64_t)(X1 - X0) * (Y2 - Y0) - (int64_t)(Y1 - Y0) * (X2 - X0);
+                if (area2 < 0) { iA = div_f(1.0f, (float)(-area2)); rec.kind = 2; }
+            }
+            rec.scr.X[0] = X0; rec.scr.X[1] = X1; rec.scr.X[2] = X2;
+            rec.scr.Y[0] = Y0; rec.scr.Y[1] = Y1; rec.scr.Y[2] = Y2;
+            rec.scr.iA = iA;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) rec.scr.rw[k] = div_f(1.0f, r.v[k].clip[3]);
+        }
+    } else if (cut) {
+        rec.kind = 3;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { rec.cut.c[k][0] = r.v[k].clip[0]; rec.cut.c[k][1] = r.v[k].clip[1]; rec.cut.c[k][2] = r.v[k].clip[3]; }
+        rec.cut.pad_ = 0.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { rec.wx[k] = r.v[k].wpos.x; rec.wy[k] = r.v[k].wpos.y; rec.n[k] = r.v[k].wnrm; }
+}
+
+// world_pos.xy and the world normal of the fragment at (px, py); false = no varyings (the pixel keeps the cleared colour)
+TOPO_HD bool resolve_pixel(const TriRecord& rec, int32_t W, int32_t H, int32_t px, int32_t py, float& wposx, float& wposy, f3& wnrm) {
+    float q0, q1, q2;
+    if (rec.kind == 1u || rec.kind == 2u) {
+        const int32_t X0 = rec.scr.X[0], Y0 = rec.scr.Y[0], X1 = rec.scr.X[1], Y1 = rec.scr.Y[1], X2 = rec.scr.X[2], Y2 = rec.scr.Y[2];
+        const int32_t cx = px * 256 + 128, cy = py * 256 + 128;
+        float b0, b1, b2;
+        if (rec.kind == 1u) {
+            b0 = (float)(TOPO_MUL24(Y2 - Y1, cx - X1) - TOPO_MUL24(X2 - X1, cy - Y1)) * rec.scr.iA;
+            b1 = (float)(TOPO_MUL24(Y0 - Y2, cx - X2) - TOPO_MUL24(X0 - X2, cy - Y2)) * rec.scr.iA;
+            b2 = (float)(TOPO_MUL24(Y1 - Y0, cx - X0) - TOPO_MUL24(X1 - X0, cy - Y0)) * rec.scr.iA;
+        } else {
+            b0 = (float)((int64_t)(Y2 - Y1) * (cx - X1) - (int64_t)(X2 - X1) * (cy - Y1)) * rec.scr.iA;
+            b1 = (float)((int64_t)(Y0 - Y2) * (cx - X2) - (int64_t)(X0 - X2) * (cy - Y2)) * rec.scr.iA;
+            b2 = (float)((int64_t)(Y1 - Y0) * (cx - X0) - (int64_t)(X1 - X0) * (cy - Y0)) * rec.scr.iA;
+        }
+        q0 = b0 * rec.scr.rw[0]; q1 = b1 * rec.scr.rw[1]; q2 = b2 * rec.scr.rw[2];
+    } else if (rec.kind == 3u) {
+        const float gx = fmaf((float)px + 0.5f, div_f(2.0f, (float)W), -1.0f);
+        const float gy = fmaf(-((float)py + 0.5f), div_f(2.0f, (float)H), 1.0f);
+        const float *c0 = rec.cut.c[0], *c1 = rec.cut.c[1], *c2 = rec.cut.c[2];      // (x, y, w)
+        q0 = fmaf(det2(c1[1], c2[2], c1[2], c2[1]), gx, fmaf(det2(c1[2], c2[0], c1[0], c2[2]), gy, det2(c1[0], c2[1], c1[1], c2[0])));
+        q1 = fmaf(det2(c2[1], c0[2], c2[2], c0[1]), gx, fmaf(det2(c2[2], c0[0], c2[0], c0[2]), gy, det2(c2[0], c0[1], c2[1], c0[0])));
+        q2 = fmaf(det2(c0[1], c1[2], c0[2], c1[1]), gx, fmaf(det2(c0[2], c1[0], c0[0], c1[2]), gy, det2(c0[0], c1[1], c0[1], c1[0])));
+    } else {
+        return false;
+    }
+    const float iq = div_f(1.0f, (q0 + q1) + q2);
+    wposx = fmaf(rec.wx[2], q2, fmaf(rec.wx[1], q1, rec.wx[0] * q0)) * iq;
+    wposy = fmaf(rec.wy[2], q2, fmaf(rec.wy[1], q1, rec.wy[0] * q0)) * iq;
+    wnrm.x = fmaf(rec.n[2].x, q2, fmaf(rec.n[1].x, q1, rec.n[0].x * q0)) * iq;
+    wnrm.y = fmaf(rec.n[2].y, q2, fmaf(rec.n[1].y, q1, rec.n[0].y * q0)) * iq;
+    wnrm.z = fmaf(rec.n[2].z, q2, fmaf(rec.n[1].z, q1, rec.n[0].z * q0)) * iq;
+    return true;
+}
+
 // ---- peak visibility (render_engine.rs:338-396; glam Mat4::project_point3 + camera.rs:12-14) ---------------
 // This is CPU code in the reference (glam, SSE2: separate multiplies and adds, true divisions), restated as is.
 // Returns true when the peak projects inside the open NDC cube; then (x_pos, y_pos) is its pixel and peak_dist the
