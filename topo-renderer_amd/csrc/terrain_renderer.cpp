@@ -451,6 +451,10 @@ int TerrainRenderer::render_frame(FrameCtx& c, hipStream_t stream, uint32_t n, c
     p.tris_per_tile = n_tiles ? 2u * (tile_w_ - 1) * (tile_h_ - 1) : 8u;
     p.div_tris = fastdiv_make(p.tris_per_tile);
     p.div_hm1 = fastdiv_make(n_tiles ? tile_h_ - 1 : 2u);
+    p.rblocks_x = (w + kResolveBlockW - 1) / kResolveBlockW;
+    p.rblocks_view = p.rblocks_x * ((h + kResolveBlockH - 1) / kResolveBlockH);
+    p.div_rblocks_x = fastdiv_make(p.rblocks_x > 1 ? p.rblocks_x : 2u);
+    p.div_rblocks_view = fastdiv_make(p.rblocks_view > 1 ? p.rblocks_view : 2u);
     {   // the cleared render target texel: Color{0, 0.71, 0.885, 1} (terrain_renderer.rs:379-384) stored as Rgba8UnormSrgb
         float thresh[256];
         for (int i = 0; i < 256; ++i) thresh[i] = bits_f(TOPO_SRGB_THRESH_BITS[i]);

@@ -12,6 +12,7 @@ namespace topo {
 // so a 1200x1200 COP90 tile gives 20 x 80 blocks with no sliver blocks.
 constexpr uint32_t kBCX = 60, kBCY = 15;
 constexpr uint32_t kVX = kBCX + 1, kVY = kBCY + 1;
+constexpr uint32_t kResolveBlockW = 64, kResolveBlockH = 16;   // k_resolve's pixel blocks
 
 struct WorkItem {          // one (view, tile, block) that survived the frustum cull
     uint32_t view_rank;    // view << 16 | tile rank (draw order)
@@ -61,6 +62,8 @@ struct FrameParams {
     uint32_t tris_per_tile;
     FastDiv div_tris, div_hm1;   // exact division by tris_per_tile / (tile_h - 1)
     uint32_t sky_c8;           // the cleared render-target texel (sRGB8-encoded clear colour)
+    uint32_t rblocks_x, rblocks_view;             // k_resolve's 64 x 16 px blocks: per row of a view, per view
+    FastDiv div_rblocks_x, div_rblocks_view;
 };
 
 struct OutputParams {

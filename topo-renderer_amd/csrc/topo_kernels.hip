@@ -264,7 +264,7 @@ __global__ __launch_bounds__(64) void k_normals_corner(const TileDev* __restrict
 // A wave takes 64 segments at a time: one coalesced read of their marks, then one 512-byte store per marked segment.
 __global__ __launch_bounds__(256) void k_clear(uint64_t* __restrict__ vis, uint8_t* __restrict__ dirty, size_t n,
                                                uint32_t* __restrict__ counters) {
-    if (blockIdx.x == 0 && threadIdx.x < 12) counters[threadIdx.x] = 0;   // queue counters and this frame's status word
+    if (blockIdx.x == 0 && threadIdx.x < 16) counters[threadIdx.x] = 0;   // queue counters and this frame's status word
     const uint32_t lane = threadIdx.x & 63;
     const size_t nseg = (n + 63) >> 6, wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwave = (size_t)gridDim.x * 4;
     for (size_t g = wave * 64; g < nseg; g += nwave * 64) {
@@ -830,25 +830,113 @@ __global__ __launch_bounds__(256) void k_raster_big(FrameParams P) {
 }
 
 // ---- resolve: fs_main for the winner of every pixel, then the post pass --------------------------------
-// One workgroup shades a 64 x 16 px block, wave w taking rows w, w + 4, w + 8, w + 12 (interleaved: the terrain/sky
-// boundary is mostly horizontal, so the four waves of a block get similar work).  Every lane reads the visibility keys
-// of its own four pixels straight into registers (512-byte row segments); the linear depths the contour taps need go to
-// LDS -- the block's own by their owners, the 1 px halo ring (clamp-to-edge) by the first 164 threads.  A block that
-// holds no terrain at all (about half of a panorama is sky) is written out as constants without any per-pixel work:
-// with every tap at depth 1 the contour term is exactly 0 and the post pass returns the cleared texel unchanged.
+// A 64 x 16 px block is shaded by one workgroup, wave w taking rows w, w + 4, w + 8, w + 12 (interleaved: the terrain/sky
+// boundary is mostly horizontal, so the four waves of a block get similar work).
+//
+// The grid is PERSISTENT (as many workgroups as are resident at once) and each workgroup walks the blocks with a static
+// stride, software-pipelined: a block's shading needs two dependent trips to memory before it can start -- the segment
+// marks that say whether anything was drawn there (about half of a panorama is sky: such a block is written out as
+// constants without reading a key; with every tap at depth 1 the contour term is exactly 0 and the post pass returns the
+// cleared texel unchanged), then the visibility keys -- and at ~1.5 us per trip under load those two waits were three
+// quarters of a block's 12 us in a one-block-per-workgroup kernel (measured: with ALL arithmetic removed it still took
+// 0.38 of its 0.50 ms).  So while block i is shaded, the keys of block i+1 are already on their way into registers (each
+// lane reads the keys of its own four pixels, 512-byte row segments; the 1 px halo ring by the first 164 threads) and so
+// are the marks of block i+2; the sRGB tables are staged into LDS once per workgroup instead of once per block.
 //
 // Winners are shared: the near field consists of triangles tens to thousands of pixels large, and two thirds of a
 // pixel's arithmetic (three vs_main, the perspective divides, the doubled area: resolve_setup) depends on the winning
 // triangle alone.  Each wave therefore lists the distinct winners of its 256 pixels -- a lane starts a new entry when
-// its id differs from its left neighbour's -- and, if they are at most 64, computes their records densely, one triangle
-// per lane, into a per-wave LDS table; the pixels then finish from the record (resolve_pixel: the same operations on the
-// same values, bit for bit).  A wave that meets more than 64 distinct winners (far field: a triangle or less per pixel)
-// shades each pixel on its own (resolve_varyings) as round 1 did for every pixel.
-constexpr int kResolveRows = 16;
-constexpr uint32_t kRecCap = 64;       // triangle records per wave
+// its id differs from its left neighbour's -- and computes their records densely, one triangle per lane, into a
+// per-wave LDS table; the pixels then finish from the record (resolve_pixel: the same operations on the same values as
+// the one-step resolve_varyings, bit for bit).  The table holds 32 records (at c4 a wave's 256 pixels share 6.7 winners
+// on average); a wave that meets more takes its rows in groups that fit, and a single row with more than that (far
+// field: a triangle or less per pixel) is shaded in one step per pixel.
+constexpr int kRPW = 4;                            // pixel rows per wave
+constexpr int kResolveRows = 4 * kRPW;
+static_assert(kResolveRows == (int)kResolveBlockH && kResolveBlockW == 64u, "the host sizes k_resolve's block grid from these");
+#ifndef TOPO_RESOLVE_RECS
+#define TOPO_RESOLVE_RECS 32
+#endif
+constexpr uint32_t kRecCap = TOPO_RESOLVE_RECS;    // triangle records per wave
 #ifndef TOPO_RESOLVE_WGS
 #define TOPO_RESOLVE_WGS 4
 #endif
+static_assert(kRPW == 4, "Row4 below names the four rows of a wave");
+// One value per row of a wave.  Named members, not an array: `r == k ? a[k] : v` over an array is folded by the compiler
+// into a load from a run-time-indexed address, which sends the whole array to scratch memory.
+template <typename T>
+struct Row4 {
+    T a, b, c, d;
+    __device__ __forceinline__ T pick(int32_t r) const { return r == 0 ? a : r == 1 ? b : r == 2 ? c : d; }      // wave-uniform r
+};
+#define TOPO_ROWS4(X) X(0, a) X(1, b) X(2, c) X(3, d)
+
+struct ResolveBlock {          // wave-uniform description of one 64 x 16 block
+    uint32_t view;
+    int32_t bx, by;            // pixel origin
+};
+__device__ __forceinline__ ResolveBlock resolve_block(const FrameParams& P, uint32_t b) {
+    const uint32_t view = P.rblocks_view > 1u ? fastdiv(b, P.div_rblocks_view) : b, in_view = b - view * P.rblocks_view;      // (fastdiv needs a divisor >= 2)
+    const uint32_t row = P.rblocks_x > 1u ? fastdiv(in_view, P.div_rblocks_x) : in_view;
+    return ResolveBlock{view, (int32_t)(in_view - row * P.rblocks_x) * 64, (int32_t)row * kResolveRows};
+}
+// Did anything write a key of the block or its halo?  Every row of block + halo spans at most three 64-key segments;
+// t < 54 names one (row, segment) mark.
+__device__ __forceinline__ bool resolve_block_marked(const FrameParams& P, const ResolveBlock& B, uint32_t t) {
+    const int32_t row = (int32_t)t / 3, k = (int32_t)t - row * 3;
+    int32_t y = B.by + row - 1;
+    y = y < 0 ? 0 : (y > P.H - 1 ? P.H - 1 : y);
+    const int32_t x0 = B.bx > 0 ? B.bx - 1 : 0, x1 = B.bx + 64 < P.W ? B.bx + 64 : P.W - 1;
+    const size_t first = (size_t)B.view * P.W * P.H + (size_t)y * P.W;
+    const size_t seg = ((first + x0) >> 6) + k;
+    const size_t last = (first + x1) >> 6;
+    const size_t at = seg <= last ? seg : last;      // (always a load, of a mark of this row: no branch around it)
+    const bool mark = TOPO_CHK(P.counters, at < (((size_t)P.n_views * P.W * P.H + 63) >> 6), 12u, at) ? P.dirty[at] != 0 : false;
+    return seg <= last && mark;
+}
+struct ResolveKeys {           // what a thread holds of a block: the keys of its own four pixels and (threads < 164) one ring key
+    Row4<uint32_t> id, raw;
+    uint32_t ring_hi;
+};
+__device__ __forceinline__ void resolve_load_keys(const FrameParams& P, const ResolveBlock& B, uint32_t lane, uint32_t wave, ResolveKeys& K) {
+    const uint64_t* vis = P.vis + (size_t)B.view * P.W * P.H;
+    const int32_t px = B.bx + (int32_t)lane;
+    // (outside the target the positions clamp to the edge; those lanes / rows only feed the contour taps' LDS tile)
+    const int32_t cx = px > P.W - 1 ? P.W - 1 : px;
+#define TOPO_X(r, m)                                                                  \
+    {                                                                                 \
+        const int32_t py = B.by + (int32_t)wave + 4 * r;                              \
+        const uint64_t key = vis[(size_t)(py > P.H - 1 ? P.H - 1 : py) * P.W + cx];   \
+        K.id.m = (uint32_t)key;                                                       \
+        K.raw.m = (uint32_t)(key >> 32);                                              \
+    }
+    TOPO_ROWS4(TOPO_X)
+#undef TOPO_X
+    K.ring_hi = 0x3F800000u;
+    if (threadIdx.x < 2 * 66 + 2 * kResolveRows) {      // the ring: rows -1 and 16 (66 entries each), columns -1 and 64 of rows 0..15
+        int32_t ly, lx;
+        if (threadIdx.x < 132) { ly = threadIdx.x < 66 ? 0 : kResolveRows + 1; lx = (int32_t)threadIdx.x % 66; }
+        else { const int32_t k = (int32_t)threadIdx.x - 132; ly = 1 + (k >> 1); lx = (k & 1) ? 65 : 0; }
+        int32_t x = B.bx + lx - 1, y = B.by + ly - 1;
+        x = x < 0 ? 0 : (x > P.W - 1 ? P.W - 1 : x);   // clamp-to-edge depth sampler (texture.rs:113-117)
+        y = y < 0 ? 0 : (y > P.H - 1 ? P.H - 1 : y);
+        K.ring_hi = (uint32_t)(vis[(size_t)y * P.W + x] >> 32);
+    }
+}
+
+constexpr uint32_t kResolveChunk = 512;      // blocks of one workgroup whose marks are looked at in one go
+
+__device__ __forceinline__ void resolve_fill_sky(const FrameParams& P, const OutputParams& O, const ResolveBlock& B, uint32_t lane, uint32_t wave) {
+    const int32_t px = B.bx + (int32_t)lane;
+    if (px >= P.W) return;
+    uint8_t* const rgba_col = O.rgba + (size_t)B.view * O.rgba_view_stride + (size_t)px * 4;
+    uint8_t* const depth_col = O.depth ? reinterpret_cast<uint8_t*>(O.depth) + (size_t)B.view * O.depth_view_stride + (size_t)px * 4 : nullptr;
+    for (int32_t ty = (int32_t)wave; ty < kResolveRows && B.by + ty < P.H; ty += 4) {
+        *reinterpret_cast<uint32_t*>(rgba_col + (size_t)(B.by + ty) * O.rgba_pitch) = P.sky_c8;
+        if (depth_col) *reinterpret_cast<float*>(depth_col + (size_t)(B.by + ty) * O.depth_pitch) = 1.0f;
+    }
+}
+
 __global__ __launch_bounds__(256, TOPO_RESOLVE_WGS) void k_resolve(FrameParams P, OutputParams O) {
     __shared__ float s_thresh[258];    // sRGB code boundaries; [255..257] = NaN: never <= anything (srgb_encode_lut probes up to 256)
     __shared__ float s_decode[256];
@@ -857,153 +945,250 @@ __global__ __launch_bounds__(256, TOPO_RESOLVE_WGS) void k_resolve(FrameParams P
     __shared__ float s_lin[kResolveRows + 2][66];            // linear depth of the block + halo
     __shared__ uint32_t s_rec[4][kTriRecordWords][kRecCap];  // per wave: the records, word-major (lanes with consecutive slots hit consecutive banks)
     __shared__ uint32_t s_uid[4][kRecCap];                   // per wave: the distinct winner ids
-    __shared__ uint32_t s_any[4];                            // per wave: did its part of the block + halo hold terrain
-    const uint32_t view_idx = blockIdx.z;
-    const uint64_t* vis = P.vis + (size_t)view_idx * P.W * P.H;
-    const int32_t bx = blockIdx.x * 64, by = blockIdx.y * kResolveRows;
+    __shared__ uint8_t s_flag[kResolveChunk];                // this chunk's blocks: was anything drawn in the block or its halo
+    __shared__ uint16_t s_marked[kResolveChunk], s_clear[kResolveChunk];      // ... sorted into the two work lists
+    __shared__ uint32_t s_count[2];
     const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int32_t tx = (int32_t)lane, px = bx + tx;
-    // every row of the block + halo spans at most three 64-key segments: if none of them is marked, nothing was drawn here
-    bool terrain = false;
-    if (threadIdx.x < (kResolveRows + 2) * 3) {
-        const int32_t row = (int32_t)threadIdx.x / 3, k = (int32_t)threadIdx.x - row * 3;
-        int32_t y = by + row - 1;
-        y = y < 0 ? 0 : (y > P.H - 1 ? P.H - 1 : y);
-        const int32_t x0 = bx > 0 ? bx - 1 : 0, x1 = bx + 64 < P.W ? bx + 64 : P.W - 1;
-        const size_t first = (size_t)(vis - P.vis) + (size_t)y * P.W;
-        const size_t seg = ((first + x0) >> 6) + k;
-        terrain = seg <= ((first + x1) >> 6) && TOPO_CHK(P.counters, seg < (((size_t)P.n_views * P.W * P.H + 63) >> 6), 12u, seg) && P.dirty[seg] != 0;
-    }
-    uint8_t* const rgba_col = O.rgba + (size_t)view_idx * O.rgba_view_stride + (size_t)px * 4;
-    uint8_t* const depth_col = O.depth ? reinterpret_cast<uint8_t*>(O.depth) + (size_t)view_idx * O.depth_view_stride + (size_t)px * 4 : nullptr;
-    if (__syncthreads_or(terrain) == 0) {        // workgroup-uniform: write the cleared texel and depth 1
-        if (px >= P.W) return;
-        for (int32_t ty = (int32_t)wave; ty < kResolveRows && by + ty < P.H; ty += 4) {
-            *reinterpret_cast<uint32_t*>(rgba_col + (size_t)(by + ty) * O.rgba_pitch) = P.sky_c8;
-            if (depth_col) *reinterpret_cast<float*>(depth_col + (size_t)(by + ty) * O.depth_pitch) = 1.0f;
-        }
-        return;
-    }
-    // ---- keys: own pixels into registers (+ their linear depth into LDS), halo ring into LDS
-    uint32_t ids[4], raws[4];
-    terrain = false;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int32_t ty = (int32_t)wave + 4 * r, py = by + ty;
-        // (outside the target the tap positions clamp to the edge; those lanes / rows only feed the LDS tile)
-        const int32_t cx = px > P.W - 1 ? P.W - 1 : px, cy = py > P.H - 1 ? P.H - 1 : py;
-        const uint64_t key = vis[(size_t)cy * P.W + cx];
-        ids[r] = (uint32_t)key;
-        raws[r] = (uint32_t)(key >> 32);
-        terrain |= raws[r] != 0x3F800000u;
-        s_lin[ty + 1][tx + 1] = linear_depth(bits_f(raws[r]));
-    }
-    if (threadIdx.x < 2 * 66 + 2 * kResolveRows) {      // the ring: rows -1 and 16 (66 entries each), columns -1 and 64 of rows 0..15
-        int32_t ly, lx;
-        if (threadIdx.x < 132) { ly = threadIdx.x < 66 ? 0 : kResolveRows + 1; lx = (int32_t)threadIdx.x % 66; }
-        else { const int32_t k = (int32_t)threadIdx.x - 132; ly = 1 + (k >> 1); lx = (k & 1) ? 65 : 0; }
-        int32_t x = bx + lx - 1, y = by + ly - 1;
-        x = x < 0 ? 0 : (x > P.W - 1 ? P.W - 1 : x);   // clamp-to-edge depth sampler (texture.rs:113-117)
-        y = y < 0 ? 0 : (y > P.H - 1 ? P.H - 1 : y);
-        const uint32_t hi = (uint32_t)(vis[(size_t)y * P.W + x] >> 32);
-        terrain |= hi != 0x3F800000u;
-        s_lin[ly][lx] = linear_depth(bits_f(hi));
-    }
-    const uint64_t any_mask = __ballot(terrain);
-    if (lane == 0) s_any[wave] = any_mask != 0 ? 1u : 0u;
+    const int32_t tx = (int32_t)lane;
+    // Blocks are dealt out with a static stride: workgroup g takes blocks g, g + grid, g + 2 grid, ... -- a sample of every
+    // part of every view, so each workgroup gets the same mix of sky, far field and near field.  (Handing out runs of
+    // consecutive blocks dynamically measured 10 % to 3.5x slower: a run is all sky or all near field, and a block takes
+    // ~10 us from first mark to last store, so whoever draws the last near-field run finishes long after everyone else.)
+    const uint32_t n_blocks = P.rblocks_view * P.n_views, stride = gridDim.x;
+    const uint32_t per_wg = (n_blocks - blockIdx.x + stride - 1) / stride;      // blocks blockIdx.x + j * stride, j < per_wg (the grid is <= n_blocks)
+    // once per workgroup: the tables
     s_thresh[threadIdx.x] = threadIdx.x < 255 ? bits_f(TOPO_SRGB_THRESH_BITS[threadIdx.x]) : NAN;
     if (threadIdx.x < 2) s_thresh[256 + threadIdx.x] = NAN;
     s_decode[threadIdx.x] = bits_f(TOPO_SRGB_DECODE_BITS[threadIdx.x]);
     s_ndec[threadIdx.x] = normal_channel(threadIdx.x);
 #pragma unroll
     for (int k = 0; k < 4; ++k) s_lut[threadIdx.x + 256 * k] = TOPO_SRGB_LUT12_WORDS[threadIdx.x + 256 * k];
-    __syncthreads();
-    const bool in_x = px < P.W;        // lanes beyond the target's right edge stay: they compute triangle records below
-    if ((s_any[0] | s_any[1] | s_any[2] | s_any[3]) == 0) {      // workgroup-uniform
-        if (!in_x) return;
-        for (int32_t ty = (int32_t)wave; ty < kResolveRows && by + ty < P.H; ty += 4) {
-            *reinterpret_cast<uint32_t*>(rgba_col + (size_t)(by + ty) * O.rgba_pitch) = P.sky_c8;
-            if (depth_col) *reinterpret_cast<float*>(depth_col + (size_t)(by + ty) * O.depth_pitch) = 1.0f;
-        }
-        return;
-    }
     const uint8_t* lut = reinterpret_cast<const uint8_t*>(s_lut);
-    const ViewDev& view = P.views[view_idx];
+#ifdef TOPO_RESOLVE_PROF      // experiment build: where do a wave's cycles go?  counters[8..15], units of 1024 cycles summed over waves
+    uint32_t pf_t = (uint32_t)__builtin_amdgcn_s_memtime(), pf_acc[7] = {0, 0, 0, 0, 0, 0, 0};
+    const uint32_t pf_start = pf_t;
+#define TOPO_PROF(slot) { const uint32_t now_ = (uint32_t)__builtin_amdgcn_s_memtime(); pf_acc[slot] += now_ - pf_t; pf_t = now_; }
+#else
+#define TOPO_PROF(slot)
+#endif
 
-    // ---- the distinct winners of this wave's pixels: a lane opens an entry where its id differs from its left neighbour's
-    uint32_t slot[4];
-    uint32_t n_uniq = 0;
+    for (uint32_t j0 = 0; j0 < per_wg; j0 += kResolveChunk) {
+        const uint32_t nj = per_wg - j0 < kResolveChunk ? per_wg - j0 : kResolveChunk;
+        // ---- which of this chunk's blocks hold anything: all their segment marks in one trip to memory
+        __syncthreads();      // (the previous chunk's lists are done with)
+        for (uint32_t j = threadIdx.x; j < nj; j += 256) s_flag[j] = 0;
+        __syncthreads();
+        constexpr uint32_t kMarks = (kResolveRows + 2) * 3;
+        for (uint32_t q0 = 0; q0 < nj * kMarks; q0 += 256 * 8) {      // eight marks per thread in flight at a time
+            bool m[8];
+            uint32_t jj[8];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const bool valid = in_x && by + (int32_t)wave + 4 * r < P.H && ids[r] != kNoTri;
-        const uint32_t left = (uint32_t)__shfl_up((int)ids[r], 1);
-        const bool leader = valid && (lane == 0 || ids[r] != left);
-        const uint64_t mask = __ballot(leader);
-        const uint32_t upto = (uint32_t)__popcll(mask & ((2ull << lane) - 1ull));      // leaders at or before this lane
-        slot[r] = n_uniq + upto - 1u;      // meaningful for valid lanes: their run's leader is the last leader at or before them
-        if (leader && slot[r] < kRecCap) s_uid[wave][slot[r]] = ids[r];
-        n_uniq += (uint32_t)__popcll(mask);
-    }
-    const bool shared = n_uniq <= kRecCap;      // wave-uniform
-    if (shared && lane < n_uniq) {
-        const uint32_t id = s_uid[wave][lane];
-        const uint32_t draw = id >> 1, fan = id & 1u;
-        const uint32_t rank = fastdiv(draw, P.div_tris), tri = draw - rank * P.tris_per_tile;
-        TriRecord rec;
-        if (TOPO_CHK(P.counters, rank < P.n_tiles, 13u, id)) resolve_setup(P.tiles[rank], P.tile_w, P.div_hm1, P.tile_h - 1, view, P.W, P.H, tri, fan, s_ndec, rec);
-        else rec.kind = 0;
-        const uint32_t* w = reinterpret_cast<const uint32_t*>(&rec);
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t q = q0 + (uint32_t)u * 256 + threadIdx.x;
+                const uint32_t qq = q < nj * kMarks ? q : 0u;      // (clamped, not skipped: the eight loads must not be chained by branches)
+                jj[u] = qq / kMarks;
+                m[u] = resolve_block_marked(P, resolve_block(P, blockIdx.x + (j0 + jj[u]) * stride), qq - jj[u] * kMarks) && q < nj * kMarks;
+            }
 #pragma unroll
-        for (int k = 0; k < kTriRecordWords; ++k) s_rec[wave][k][lane] = w[k];
+            for (int u = 0; u < 8; ++u)
+                if (m[u]) s_flag[jj[u]] = 1;      // racing writers agree
+        }
+        __syncthreads();
+        if (wave == 0) {      // the two work lists, in block order
+            uint32_t nm = 0, nc = 0;
+            for (uint32_t j = 0; j < nj; j += 64) {
+                const bool in = j + lane < nj, m = in && s_flag[j + lane] != 0;
+                const uint64_t mm = __ballot(m), mc = __ballot(in && !m), lt = (1ull << lane) - 1ull;
+                if (m) s_marked[nm + (uint32_t)__popcll(mm & lt)] = (uint16_t)(j + lane);
+                else if (in) s_clear[nc + (uint32_t)__popcll(mc & lt)] = (uint16_t)(j + lane);
+                nm += (uint32_t)__popcll(mm);
+                nc += (uint32_t)__popcll(mc);
+            }
+            if (lane == 0) { s_count[0] = nm; s_count[1] = nc; }
+        }
+        __syncthreads();
+        const uint32_t n_marked = s_count[0], n_clear = s_count[1];
+        TOPO_PROF(0)      // marks + lists
+        // (the list entries come out of LDS: tell the compiler they are wave-uniform, or every address derived from a
+        // block's origin becomes per-lane arithmetic and every load of its view's constants a vector load)
+        auto block_of = [&](uint32_t j) { return resolve_block(P, blockIdx.x + (j0 + uni(j)) * stride); };
+        // the untouched blocks are pure stores: spread over the marked blocks' iterations, so that their bandwidth hides
+        // under the shading
+        const uint32_t fills_per_iter = n_marked ? (n_clear + n_marked - 1) / n_marked : n_clear;
+        uint32_t ci = 0;
+        ResolveKeys K;
+        if (n_marked) resolve_load_keys(P, block_of(s_marked[0]), lane, wave, K);
+        for (uint32_t i = 0; i < (n_marked ? n_marked : 1u); ++i) {
+            ResolveKeys Kn;
+            if (i + 1 < n_marked) resolve_load_keys(P, block_of(s_marked[i + 1]), lane, wave, Kn);      // in flight while block i is shaded
+            for (uint32_t f = 0; f < fills_per_iter && ci < n_clear; ++f, ++ci) resolve_fill_sky(P, O, block_of(s_clear[ci]), lane, wave);
+            TOPO_PROF(1)  // issue of the next keys + sky fills
+            if (i >= n_marked) break;
+            const ResolveBlock B = block_of(s_marked[i]);
+            const int32_t px = B.bx + tx;
+            const bool in_x = px < P.W;        // lanes beyond the target's right edge stay: they compute triangle records
+            uint8_t* const rgba_col = O.rgba + (size_t)B.view * O.rgba_view_stride + (size_t)px * 4;
+            uint8_t* const depth_col = O.depth ? reinterpret_cast<uint8_t*>(O.depth) + (size_t)B.view * O.depth_view_stride + (size_t)px * 4 : nullptr;
+            const Row4<uint32_t> ids = K.id, raws = K.raw;
+            const bool terrain = raws.a != 0x3F800000u || raws.b != 0x3F800000u || raws.c != 0x3F800000u || raws.d != 0x3F800000u || K.ring_hi != 0x3F800000u;
+            TOPO_PROF(2)  // wait for this block's keys
+            __syncthreads();                    // every wave is done with the previous block's linear depths
+            TOPO_PROF(3)  // barrier: the slowest wave of the previous block
+#define TOPO_X(r, m) s_lin[(int32_t)wave + 4 * r + 1][tx + 1] = linear_depth(bits_f(raws.m));
+            TOPO_ROWS4(TOPO_X)
+#undef TOPO_X
+            if (threadIdx.x < 2 * 66 + 2 * kResolveRows) {
+                int32_t ly, lx;
+                if (threadIdx.x < 132) { ly = threadIdx.x < 66 ? 0 : kResolveRows + 1; lx = (int32_t)threadIdx.x % 66; }
+                else { const int32_t k = (int32_t)threadIdx.x - 132; ly = 1 + (k >> 1); lx = (k & 1) ? 65 : 0; }
+                s_lin[ly][lx] = linear_depth(bits_f(K.ring_hi));
+            }
+            const bool any_terrain = __syncthreads_or(terrain) != 0;      // also publishes s_lin
+            TOPO_PROF(4)  // linear depths + barrier
+            if (!any_terrain) {                // marked, but every key still cleared (a mark covers 64 keys): the cleared texel and depth 1
+                resolve_fill_sky(P, O, B, lane, wave);
+                K = Kn;
+                continue;
+            }
+            const ViewDev& view = P.views[B.view];
+            // what fs_main reads of the view, once per block and wave-uniform: left to the compiler these are re-loaded in every
+            // row (it cannot prove the output stores do not alias them) behind an s_waitcnt vmcnt(0) that also waits for the
+            // previous row's stores to land
+            const f3 sun = {unif(view.sun[0]), unif(view.sun[1]), unif(view.sun[2])};
+            const float cam_x = unif(view.cam_x), cam_y = unif(view.cam_y);
+            const int32_t view_mode = uni(view.view_mode);
+            // ---- the distinct winners of this wave's pixels: a lane opens an entry where its id differs from its left
+            // neighbour's.  slot[r] = the entry of the lane's pixel in row r, counted over the whole wave; n_row[r] = entries of row r.
+            Row4<uint32_t> slot, n_row;
+            uint32_t leaders = 0;              // bit r: this lane opens an entry in row r
+            {
+                uint32_t n = 0;
+#define TOPO_X(r, m)                                                                                                                   \
+    {                                                                                                                                  \
+        const bool valid = in_x && B.by + (int32_t)wave + 4 * r < P.H && ids.m != kNoTri;                                              \
+        const uint32_t left = (uint32_t)__shfl_up((int)ids.m, 1);                                                                      \
+        const bool leader = valid && (lane == 0 || ids.m != left);                                                                     \
+        const uint64_t mask = __ballot(leader);                                                                                        \
+        slot.m = n + (uint32_t)__popcll(mask & ((2ull << lane) - 1ull)) - 1u; /* valid lanes: the last leader at or before them */      \
+        leaders |= leader ? (1u << r) : 0u;                                                                                            \
+        n_row.m = (uint32_t)__popcll(mask);                                                                                            \
+        n += n_row.m;                                                                                                                  \
     }
-    // (the table is read only by the wave that wrote it: LDS operations of one wave complete in order)
-
+                TOPO_ROWS4(TOPO_X)
+#undef TOPO_X
+            }
+#ifdef TOPO_RESOLVE_STATS      // experiment build: how well do winners share?  counters[12] entries, [13] waves with terrain, [14] groups, [15] terrain pixels
+            {
+                uint32_t n_all = 0, npx = 0;
+#define TOPO_X(r, m) n_all += n_row.m; npx += (uint32_t)__popcll(__ballot(in_x && ids.m != kNoTri));
+                TOPO_ROWS4(TOPO_X)
+#undef TOPO_X
+                if (lane == 0 && n_all) { atomicAdd(&P.counters[12], n_all); atomicAdd(&P.counters[13], 1u); atomicAdd(&P.counters[15], npx); }
+            }
+#endif
+            // Rows are taken in groups of consecutive rows whose entries fit the table.  Near field: all four rows in one
+            // group, a handful of records.
+            int32_t r0 = 0;
+            uint32_t gbase = 0;
 #pragma unroll 1
-    for (int r = 0; r < 4; ++r) {
-        const int32_t ty = (int32_t)wave + 4 * r, py = by + ty;
-        if (py >= P.H) break;
-        const uint32_t id = in_x ? ids[r] : kNoTri;
-        // render target texel (Rgba8UnormSrgb): the cleared value or the shaded winner
-        uint32_t c8 = P.sky_c8;
-        if (id != kNoTri) {
-            float lin[4] = {0.0f, 0.71f, 0.885f, 1.0f};
-            f3 wpos = {0.0f, 0.0f, 0.0f}, wnrm;
-            bool ok;
-            if (shared) {
-                TriRecord rec;
-                uint32_t* w = reinterpret_cast<uint32_t*>(&rec);
-                const uint32_t sl = slot[r];
+            while (r0 < kRPW) {
+                int32_t r1 = r0;
+                uint32_t cnt = 0;
+#define TOPO_X(r, m) if (r >= r0 && r == r1 && cnt + n_row.m <= kRecCap) { cnt += n_row.m; r1 = r + 1; }
+                TOPO_ROWS4(TOPO_X)
+#undef TOPO_X
+                // a single row with more distinct winners than the table holds (far field, a triangle per pixel): that row is
+                // shaded pixel by pixel in one step (resolve_varyings), as every row was in round 1
+                const bool table = r1 > r0;
+                if (!table) {
+                    r1 = r0 + 1;
+                    cnt = n_row.pick(r0);
+                }
+#ifdef TOPO_RESOLVE_STATS
+                if (lane == 0 && cnt) atomicAdd(&P.counters[14], 1u);
+#endif
+                // the group's winner ids, pushed by the lanes that opened the entries
+#define TOPO_X(r, m) if (table && r >= r0 && r < r1 && (leaders >> r & 1u)) s_uid[wave][slot.m - gbase] = ids.m;
+                TOPO_ROWS4(TOPO_X)
+#undef TOPO_X
+                if (table && lane < cnt) {      // one triangle per lane: everything that depends on the triangle alone
+                    const uint32_t id = s_uid[wave][lane];
+                    const uint32_t draw = id >> 1, fan = id & 1u;
+                    const uint32_t rank = fastdiv(draw, P.div_tris), tri = draw - rank * P.tris_per_tile;
+                    TriRecord rec;
+                    if (TOPO_CHK(P.counters, rank < P.n_tiles, 13u, id)) resolve_setup(P.tiles[rank], P.tile_w, P.div_hm1, P.tile_h - 1, view, P.W, P.H, tri, fan, s_ndec, rec);
+                    else rec = TriRecord{};
+                    int k = 0;
+#define TOPO_X(f) s_rec[wave][k++][lane] = rec.f;
+                    TOPO_TRIREC_WORDS(TOPO_X)
+#undef TOPO_X
+                }
+                TOPO_PROF(5)  // winners: entries, records (gathers)
+                // (the table is written and read by the same wave: the LDS operations of one wave complete in order)
+#pragma unroll 1
+                for (int32_t r = r0; r < r1; ++r) {
+                    const int32_t ty = (int32_t)wave + 4 * r, py = B.by + ty;
+                    if (py >= P.H) break;
+                    // (r is wave-uniform: pick() is scalar-conditioned moves)
+                    const uint32_t id_r = ids.pick(r), raw_r = raws.pick(r), sl = slot.pick(r) - gbase;
+                    const uint32_t id = in_x ? id_r : kNoTri;
+                    // the contour taps first: they depend on nothing, so their LDS trip overlaps the record's
+                    float ln[8];
+                    {
+                        int k = 0;
 #pragma unroll
-                for (int k = 0; k < kTriRecordWords; ++k) w[k] = s_rec[wave][k][sl];
-                ok = resolve_pixel(rec, P.W, P.H, px, py, wpos.x, wpos.y, wnrm);
-            } else {
-                const uint32_t draw = id >> 1, fan = id & 1u;
-                const uint32_t rank = fastdiv(draw, P.div_tris), tri = draw - rank * P.tris_per_tile;
-                ok = TOPO_CHK(P.counters, rank < P.n_tiles, 13u, id) &&
-                     resolve_varyings(P.tiles[rank], P.tile_w, P.div_hm1, P.tile_h - 1, view, P.W, P.H, tri, fan, s_ndec, px, py, wpos, wnrm);
+                        for (int i = -1; i <= 1; ++i)
+#pragma unroll
+                            for (int j = -1; j <= 1; ++j) {
+                                if (i == 0 && j == 0) continue;
+                                ln[k++] = s_lin[ty + 1 + j][tx + 1 + i];
+                            }
+                    }
+                    const float lin_c = s_lin[ty + 1][tx + 1];
+                    // render target texel (Rgba8UnormSrgb): the cleared value or the shaded winner
+                    uint32_t c8 = P.sky_c8;
+                    if (id != kNoTri) {
+                        float lin[4] = {0.0f, 0.71f, 0.885f, 1.0f};
+                        f3 wpos = {0.0f, 0.0f, 0.0f}, wnrm;
+                        bool ok;
+                        if (table) {
+                            TriRecord rec;
+                            int k = 0;
+#define TOPO_X(f) rec.f = s_rec[wave][k++][sl];
+                            TOPO_TRIREC_WORDS(TOPO_X)
+#undef TOPO_X
+                            ok = resolve_pixel(rec, P.W, P.H, px, py, wpos.x, wpos.y, wnrm);
+                        } else {
+                            const uint32_t draw = id >> 1, fan = id & 1u;
+                            const uint32_t rank = fastdiv(draw, P.div_tris), tri = draw - rank * P.tris_per_tile;
+                            ok = TOPO_CHK(P.counters, rank < P.n_tiles, 13u, id) &&
+                                 resolve_varyings(P.tiles[rank], P.tile_w, P.div_hm1, P.tile_h - 1, view, P.W, P.H, tri, fan, s_ndec, px, py, wpos, wnrm);
+                        }
+                        if (ok) shade_fragment(view_mode, sun, cam_x, cam_y, (float)px + 0.5f, (float)py + 0.5f, wpos, wnrm, lin);
+                        c8 = srgb_encode_lut3(s_thresh, lut, lin[0], lin[1], lin[2]) | (to_unorm8(lin[3]) << 24);
+                    }
+                    const uint32_t out = post_pixel_t<true>(s_thresh, s_decode, c8, lin_c, ln, lut);
+                    if (in_x) {
+                        *reinterpret_cast<uint32_t*>(rgba_col + (size_t)py * O.rgba_pitch) = out;
+                        if (depth_col) *reinterpret_cast<uint32_t*>(depth_col + (size_t)py * O.depth_pitch) = raw_r;
+                    }
+                }
+                TOPO_PROF(6)  // pixels
+                gbase += cnt;
+                r0 = r1;
             }
-            if (ok) {
-                const f3 sun = {view.sun[0], view.sun[1], view.sun[2]};
-                shade_fragment(view.view_mode, sun, view.cam_x, view.cam_y, (float)px + 0.5f, (float)py + 0.5f, wpos, wnrm, lin);
-            }
-            c8 = srgb_encode_lut(s_thresh, lut, lin[0]) | (srgb_encode_lut(s_thresh, lut, lin[1]) << 8) |
-                 (srgb_encode_lut(s_thresh, lut, lin[2]) << 16) | (to_unorm8(lin[3]) << 24);
+            K = Kn;
         }
-        float ln[8];
-        int k = 0;
-#pragma unroll
-        for (int i = -1; i <= 1; ++i)
-#pragma unroll
-            for (int j = -1; j <= 1; ++j) {
-                if (i == 0 && j == 0) continue;
-                ln[k++] = s_lin[ty + 1 + j][tx + 1 + i];
-            }
-        const uint32_t out = post_pixel_t<true>(s_thresh, s_decode, c8, s_lin[ty + 1][tx + 1], ln, lut);
-        if (in_x) {
-            *reinterpret_cast<uint32_t*>(rgba_col + (size_t)py * O.rgba_pitch) = out;
-            if (depth_col) *reinterpret_cast<uint32_t*>(depth_col + (size_t)py * O.depth_pitch) = raws[r];
-        }
+        for (; ci < n_clear; ++ci) resolve_fill_sky(P, O, block_of(s_clear[ci]), lane, wave);
+        TOPO_PROF(1)
     }
+#ifdef TOPO_RESOLVE_PROF
+    if (lane == 0) {
+        for (int k = 0; k < 7; ++k) atomicAdd(&P.counters[9 + k], pf_acc[k] >> 10);
+        atomicAdd(&P.counters[8], ((uint32_t)__builtin_amdgcn_s_memtime() - pf_start) >> 10);
+    }
+#endif
+#undef TOPO_PROF
 }
 
 // One lane per peak: project, one depth lookup, one comparison (render_engine.rs:338-396).
@@ -1196,7 +1381,11 @@ void launch_raster_big(const FrameParams& p, hipStream_t s) {
 }
 
 void launch_resolve(const FrameParams& p, const OutputParams& o, hipStream_t s) {
-    hipLaunchKernelGGL(k_resolve, dim3((p.W + 63) / 64, (p.H + kResolveRows - 1) / kResolveRows, p.n_views), dim3(256), 0, s, p, o);
+    const unsigned n_blocks = p.rblocks_view * p.n_views;
+    if (n_blocks == 0) return;
+    unsigned resident = resident_grid<3>(k_resolve, 256 * TOPO_RESOLVE_WGS);
+    if (const char* e = getenv("TOPO_RESOLVE_GRID")) resident = (unsigned)atoi(e) ? (unsigned)atoi(e) : n_blocks;      // experiments: 0 = one block per workgroup
+    hipLaunchKernelGGL(k_resolve, dim3(n_blocks < resident ? n_blocks : resident), dim3(256), 0, s, p, o);
 }
 
 void launch_visible_peaks(const float* proj16_dev, uint32_t w, uint32_t h, const float* depth, size_t depth_pitch, uint32_t n,

@@ -250,6 +250,18 @@ TOPO_HD uint32_t srgb_encode_lut(const float* thresh, const uint8_t* lut, float 
     return base + (thresh[base] <= l ? 1u : 0u) + (thresh[base + 1] <= l ? 1u : 0u);
 }
 
+// Three channels at once, written so that the three table lookups of each stage are independent and in flight together
+// (one after the other, each encode is two dependent LDS round trips: six per pixel; this way two).
+TOPO_HD uint32_t srgb_encode_lut3(const float* thresh, const uint8_t* lut, float r, float g, float b) {
+    const uint32_t br = (uint32_t)fminf(fmaxf(r * 4096.0f, 0.0f), 4095.0f), bg = (uint32_t)fminf(fmaxf(g * 4096.0f, 0.0f), 4095.0f),
+                   bb = (uint32_t)fminf(fmaxf(b * 4096.0f, 0.0f), 4095.0f);
+    const uint32_t ar = lut[br], ag = lut[bg], ab = lut[bb];
+    const float r0 = thresh[ar], r1 = thresh[ar + 1], g0 = thresh[ag], g1 = thresh[ag + 1], b0 = thresh[ab], b1 = thresh[ab + 1];
+    const uint32_t cr = ar + (r0 <= r ? 1u : 0u) + (r1 <= r ? 1u : 0u), cg = ag + (g0 <= g ? 1u : 0u) + (g1 <= g ? 1u : 0u),
+                   cb = ab + (b0 <= b ? 1u : 0u) + (b1 <= b ? 1u : 0u);
+    return cr | (cg << 8) | (cb << 16);
+}
+
 // ---- normal stencil (compute_normals*.wgsl) ------------------------------------------------------
 // Returns the packed rgba8unorm texel (alpha 0) for the four neighbour heights; `x`,`y` are the metric
 // half-steps the shaders build from the pixel scale and the row latitude.
@@ -327,9 +339,7 @@ TOPO_HD uint32_t post_pixel_t(const float* thresh, const float* decode, uint32_t
     const float g = decode[(c8 >> 8) & 255u] * (1.0f - a) + 0.0f * a;
     const float b = decode[(c8 >> 16) & 255u] * (1.0f - a) + 0.0f * a;
     const float al = from_unorm8(c8 >> 24) * (1.0f - a) + 1.0f * a;
-    if (kLut)
-        return srgb_encode_lut(thresh, lut, r) | (srgb_encode_lut(thresh, lut, g) << 8) | (srgb_encode_lut(thresh, lut, b) << 16) |
-               (to_unorm8(al) << 24);
+    if (kLut) return srgb_encode_lut3(thresh, lut, r, g, b) | (to_unorm8(al) << 24);
     return srgb_encode(thresh, r) | (srgb_encode(thresh, g) << 8) | (srgb_encode(thresh, b) << 16) |
            (to_unorm8(al) << 24);
 }

@@ -545,19 +545,27 @@ TOPO_HD bool resolve_vertices(const TileDev& t, uint32_t tile_w, FastDiv div_hm1
     const uint32_t cell = tri >> 1, k = tri & 1u;
     const uint32_t ci = fastdiv(cell, div_hm1), cj = cell - ci * hm1;
     const bool even = ((ci + cj) & 1u) == 0;
-    const auto tlon = TOPO_GLOBAL_F32(t.trig_lon) + 2 * ci;
-    const auto tlat = TOPO_GLOBAL_F32(t.trig_lat) + 2 * cj;
-    const float slo0 = tlon[0], clo0 = tlon[1], slo1 = tlon[2], clo1 = tlon[3];
-    const float sla0 = tlat[0], cla0 = tlat[1], sla1 = tlat[2], cla1 = tlat[3];
     // corner offsets (render_buffer.rs:191-219): k=0: a, b, (even ? d : c);  k=1: d, c, (even ? a : b)
     const uint32_t ox[3] = {k, k, 1u - k};
     const uint32_t oy[3] = {k, 1u - k, k == 0 ? (even ? 1u : 0u) : (even ? 0u : 1u)};
+    // Every load first, then the arithmetic: the three heights, three normals and eight table entries depend on nothing
+    // but the tile descriptor, so they travel together (one trip to memory instead of one per vertex).
+    const auto tlon = TOPO_GLOBAL_F32(t.trig_lon) + 2 * ci;
+    const auto tlat = TOPO_GLOBAL_F32(t.trig_lat) + 2 * cj;
+    const auto hts = TOPO_GLOBAL_F32(t.heights);
+    const auto nrm = TOPO_GLOBAL_U32(t.normals);
+    const size_t idx0 = (size_t)(cj + oy[0]) * tile_w + (ci + ox[0]), idx1 = (size_t)(cj + oy[1]) * tile_w + (ci + ox[1]),
+                 idx2 = (size_t)(cj + oy[2]) * tile_w + (ci + ox[2]);
+    const float h0 = hts[idx0], h1 = hts[idx1], h2 = hts[idx2];
+    const uint32_t n0 = nrm[idx0], n1 = nrm[idx1], n2 = nrm[idx2];
+    const float slo0 = tlon[0], clo0 = tlon[1], slo1 = tlon[2], clo1 = tlon[3];
+    const float sla0 = tlat[0], cla0 = tlat[1], sla1 = tlat[2], cla1 = tlat[3];
+    const float hq[3] = {h0, h1, h2};
+    const uint32_t nq[3] = {n0, n1, n2};
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
-        const size_t idx = (size_t)(cj + oy[q]) * tile_w + (ci + ox[q]);
-        r.v[q].wpos = world_from_sincos(TOPO_GLOBAL_F32(t.heights)[idx], oy[q] ? sla1 : sla0, oy[q] ? cla1 : cla0, ox[q] ? slo1 : slo0,
-                                        ox[q] ? clo1 : clo0);
-        r.v[q].wnrm = vertex_normal(t, TOPO_GLOBAL_U32(t.normals)[idx], ndec);
+        r.v[q].wpos = world_from_sincos(hq[q], oy[q] ? sla1 : sla0, oy[q] ? cla1 : cla0, ox[q] ? slo1 : slo0, ox[q] ? clo1 : clo0);
+        r.v[q].wnrm = vertex_normal(t, nq[q], ndec);
         mat4_point(view.proj, r.v[q].wpos.x, r.v[q].wpos.y, r.v[q].wpos.z, r.v[q].clip);
     }
     const bool all_in = r.v[0].clip[2] >= 0.0f && r.v[1].clip[2] >= 0.0f && r.v[2].clip[2] >= 0.0f;
@@ -607,17 +615,20 @@ TOPO_HD bool resolve_varyings(const TileDev& t, uint32_t tile_w, FastDiv div_hm1
 // resolve_setup() computes that part into a 26-word record; resolve_pixel() finishes a pixel from the record with the
 // SAME operations on the same values as resolve_varyings (so the two routes agree bit for bit:
 // tests/test_emul_cpu.py::test_split_resolve_equals_resolve_varyings, and k_resolve uses either route per wave).
+// The record is 26 plain 32-bit words with names (floats as their bit patterns) and no arrays or unions in it: the
+// compiler keeps such a struct in registers, whereas word-indexed access to a union ends up in scratch memory.
+//   kind 1 / 2 (uncut, int32 / int64 barycentrics): u0..u5 = X0 X1 X2 Y0 Y1 Y2 (snapped vertices, int32),
+//                                                    u6..u8 = 1 / w_k, u9 = 1 / |doubled area|
+//   kind 3 (primitive cut by the near plane):        u0..u8 = (clip.x, clip.y, clip.w) of vertices 0, 1, 2   (homogeneous_weights)
+//   kind 0: no varyings (cannot happen for an id that won a pixel; the pixel then keeps the cleared colour)
+//   wx, wy: world position x, y of the three vertices (fs_main reads world_pos.xy only); n: world normals
+#define TOPO_TRIREC_WORDS(X)                                                                                      \
+    X(u0) X(u1) X(u2) X(u3) X(u4) X(u5) X(u6) X(u7) X(u8) X(u9) X(wx0) X(wx1) X(wx2) X(wy0) X(wy1) X(wy2) X(n0x) \
+    X(n0y) X(n0z) X(n1x) X(n1y) X(n1z) X(n2x) X(n2y) X(n2z) X(kind)
 struct TriRecord {
-    // kind 1 / 2 (uncut, int32 / int64 barycentrics): X,Y = snapped vertices, rw = 1 / w_k, iA = 1 / |doubled area|
-    // kind 3 (primitive cut by the near plane): c[k] = (clip.x, clip.y, clip.w) of vertex k  (homogeneous_weights)
-    // kind 0: no varyings (cannot happen for an id that won a pixel; the pixel then keeps the cleared colour)
-    union {
-        struct { int32_t X[3], Y[3]; float rw[3]; float iA; } scr;
-        struct { float c[3][3]; float pad_; } cut;
-    };
-    float wx[3], wy[3];       // world position x, y of the three vertices (fs_main reads world_pos.xy only)
-    f3 n[3];                  // world normals
-    uint32_t kind;
+#define TOPO_X(f) uint32_t f;
+    TOPO_TRIREC_WORDS(TOPO_X)
+#undef TOPO_X
 };
 constexpr int kTriRecordWords = 26;
 static_assert(sizeof(TriRecord) == kTriRecordWords * 4, "TriRecord is stored word by word");
@@ -627,6 +638,7 @@ TOPO_HD void resolve_setup(const TileDev& t, uint32_t tile_w, FastDiv div_hm1, u
     ResolvedTri r;
     bool cut = false;
     rec.kind = 0;
+    rec.u0 = rec.u1 = rec.u2 = rec.u3 = rec.u4 = rec.u5 = rec.u6 = rec.u7 = rec.u8 = rec.u9 = 0;
     if (resolve_vertices<true>(t, tile_w, div_hm1, hm1, view, W, H, tri, fan, ndec, r, &cut)) {
         if (fan == 0) {
             const int32_t X0 = r.s[0].X, Y0 = r.s[0].Y, X1 = r.s[1].X, Y1 = r.s[1].Y, X2 = r.s[2].X, Y2 = r.s[2].Y;
@@ -638,55 +650,61 @@ TOPO_HD void resolve_setup(const TileDev& t, uint32_t tile_w, FastDiv div_hm1, u
                 const int64_t area2 = (int64_t)(X1 - X0) * (Y2 - Y0) - (int64_t)(Y1 - Y0) * (X2 - X0);
                 if (area2 < 0) { iA = div_f(1.0f, (float)(-area2)); rec.kind = 2; }
             }
-            rec.scr.X[0] = X0; rec.scr.X[1] = X1; rec.scr.X[2] = X2;
-            rec.scr.Y[0] = Y0; rec.scr.Y[1] = Y1; rec.scr.Y[2] = Y2;
-            rec.scr.iA = iA;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) rec.scr.rw[k] = div_f(1.0f, r.v[k].clip[3]);
+            rec.u0 = (uint32_t)X0; rec.u1 = (uint32_t)X1; rec.u2 = (uint32_t)X2;
+            rec.u3 = (uint32_t)Y0; rec.u4 = (uint32_t)Y1; rec.u5 = (uint32_t)Y2;
+            rec.u6 = f_bits(div_f(1.0f, r.v[0].clip[3]));
+            rec.u7 = f_bits(div_f(1.0f, r.v[1].clip[3]));
+            rec.u8 = f_bits(div_f(1.0f, r.v[2].clip[3]));
+            rec.u9 = f_bits(iA);
         }
     } else if (cut) {
         rec.kind = 3;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { rec.cut.c[k][0] = r.v[k].clip[0]; rec.cut.c[k][1] = r.v[k].clip[1]; rec.cut.c[k][2] = r.v[k].clip[3]; }
-        rec.cut.pad_ = 0.0f;
+        rec.u0 = f_bits(r.v[0].clip[0]); rec.u1 = f_bits(r.v[0].clip[1]); rec.u2 = f_bits(r.v[0].clip[3]);
+        rec.u3 = f_bits(r.v[1].clip[0]); rec.u4 = f_bits(r.v[1].clip[1]); rec.u5 = f_bits(r.v[1].clip[3]);
+        rec.u6 = f_bits(r.v[2].clip[0]); rec.u7 = f_bits(r.v[2].clip[1]); rec.u8 = f_bits(r.v[2].clip[3]);
     }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { rec.wx[k] = r.v[k].wpos.x; rec.wy[k] = r.v[k].wpos.y; rec.n[k] = r.v[k].wnrm; }
+    rec.wx0 = f_bits(r.v[0].wpos.x); rec.wx1 = f_bits(r.v[1].wpos.x); rec.wx2 = f_bits(r.v[2].wpos.x);
+    rec.wy0 = f_bits(r.v[0].wpos.y); rec.wy1 = f_bits(r.v[1].wpos.y); rec.wy2 = f_bits(r.v[2].wpos.y);
+    rec.n0x = f_bits(r.v[0].wnrm.x); rec.n0y = f_bits(r.v[0].wnrm.y); rec.n0z = f_bits(r.v[0].wnrm.z);
+    rec.n1x = f_bits(r.v[1].wnrm.x); rec.n1y = f_bits(r.v[1].wnrm.y); rec.n1z = f_bits(r.v[1].wnrm.z);
+    rec.n2x = f_bits(r.v[2].wnrm.x); rec.n2y = f_bits(r.v[2].wnrm.y); rec.n2z = f_bits(r.v[2].wnrm.z);
 }
 
 // world_pos.xy and the world normal of the fragment at (px, py); false = no varyings (the pixel keeps the cleared colour)
 TOPO_HD bool resolve_pixel(const TriRecord& rec, int32_t W, int32_t H, int32_t px, int32_t py, float& wposx, float& wposy, f3& wnrm) {
     float q0, q1, q2;
     if (rec.kind == 1u || rec.kind == 2u) {
-        const int32_t X0 = rec.scr.X[0], Y0 = rec.scr.Y[0], X1 = rec.scr.X[1], Y1 = rec.scr.Y[1], X2 = rec.scr.X[2], Y2 = rec.scr.Y[2];
+        const int32_t X0 = (int32_t)rec.u0, X1 = (int32_t)rec.u1, X2 = (int32_t)rec.u2, Y0 = (int32_t)rec.u3, Y1 = (int32_t)rec.u4, Y2 = (int32_t)rec.u5;
         const int32_t cx = px * 256 + 128, cy = py * 256 + 128;
+        const float iA = bits_f(rec.u9);
         float b0, b1, b2;
         if (rec.kind == 1u) {
-            b0 = (float)(TOPO_MUL24(Y2 - Y1, cx - X1) - TOPO_MUL24(X2 - X1, cy - Y1)) * rec.scr.iA;
-            b1 = (float)(TOPO_MUL24(Y0 - Y2, cx - X2) - TOPO_MUL24(X0 - X2, cy - Y2)) * rec.scr.iA;
-            b2 = (float)(TOPO_MUL24(Y1 - Y0, cx - X0) - TOPO_MUL24(X1 - X0, cy - Y0)) * rec.scr.iA;
+            b0 = (float)(TOPO_MUL24(Y2 - Y1, cx - X1) - TOPO_MUL24(X2 - X1, cy - Y1)) * iA;
+            b1 = (float)(TOPO_MUL24(Y0 - Y2, cx - X2) - TOPO_MUL24(X0 - X2, cy - Y2)) * iA;
+            b2 = (float)(TOPO_MUL24(Y1 - Y0, cx - X0) - TOPO_MUL24(X1 - X0, cy - Y0)) * iA;
         } else {
-            b0 = (float)((int64_t)(Y2 - Y1) * (cx - X1) - (int64_t)(X2 - X1) * (cy - Y1)) * rec.scr.iA;
-            b1 = (float)((int64_t)(Y0 - Y2) * (cx - X2) - (int64_t)(X0 - X2) * (cy - Y2)) * rec.scr.iA;
-            b2 = (float)((int64_t)(Y1 - Y0) * (cx - X0) - (int64_t)(X1 - X0) * (cy - Y0)) * rec.scr.iA;
+            b0 = (float)((int64_t)(Y2 - Y1) * (cx - X1) - (int64_t)(X2 - X1) * (cy - Y1)) * iA;
+            b1 = (float)((int64_t)(Y0 - Y2) * (cx - X2) - (int64_t)(X0 - X2) * (cy - Y2)) * iA;
+            b2 = (float)((int64_t)(Y1 - Y0) * (cx - X0) - (int64_t)(X1 - X0) * (cy - Y0)) * iA;
         }
-        q0 = b0 * rec.scr.rw[0]; q1 = b1 * rec.scr.rw[1]; q2 = b2 * rec.scr.rw[2];
+        q0 = b0 * bits_f(rec.u6); q1 = b1 * bits_f(rec.u7); q2 = b2 * bits_f(rec.u8);
     } else if (rec.kind == 3u) {
         const float gx = fmaf((float)px + 0.5f, div_f(2.0f, (float)W), -1.0f);
         const float gy = fmaf(-((float)py + 0.5f), div_f(2.0f, (float)H), 1.0f);
-        const float *c0 = rec.cut.c[0], *c1 = rec.cut.c[1], *c2 = rec.cut.c[2];      // (x, y, w)
-        q0 = fmaf(det2(c1[1], c2[2], c1[2], c2[1]), gx, fmaf(det2(c1[2], c2[0], c1[0], c2[2]), gy, det2(c1[0], c2[1], c1[1], c2[0])));
-        q1 = fmaf(det2(c2[1], c0[2], c2[2], c0[1]), gx, fmaf(det2(c2[2], c0[0], c2[0], c0[2]), gy, det2(c2[0], c0[1], c2[1], c0[0])));
-        q2 = fmaf(det2(c0[1], c1[2], c0[2], c1[1]), gx, fmaf(det2(c0[2], c1[0], c0[0], c1[2]), gy, det2(c0[0], c1[1], c0[1], c1[0])));
+        const float c0x = bits_f(rec.u0), c0y = bits_f(rec.u1), c0w = bits_f(rec.u2), c1x = bits_f(rec.u3), c1y = bits_f(rec.u4), c1w = bits_f(rec.u5);
+        const float c2x = bits_f(rec.u6), c2y = bits_f(rec.u7), c2w = bits_f(rec.u8);
+        q0 = fmaf(det2(c1y, c2w, c1w, c2y), gx, fmaf(det2(c1w, c2x, c1x, c2w), gy, det2(c1x, c2y, c1y, c2x)));
+        q1 = fmaf(det2(c2y, c0w, c2w, c0y), gx, fmaf(det2(c2w, c0x, c2x, c0w), gy, det2(c2x, c0y, c2y, c0x)));
+        q2 = fmaf(det2(c0y, c1w, c0w, c1y), gx, fmaf(det2(c0w, c1x, c0x, c1w), gy, det2(c0x, c1y, c0y, c1x)));
     } else {
         return false;
     }
     const float iq = div_f(1.0f, (q0 + q1) + q2);
-    wposx = fmaf(rec.wx[2], q2, fmaf(rec.wx[1], q1, rec.wx[0] * q0)) * iq;
-    wposy = fmaf(rec.wy[2], q2, fmaf(rec.wy[1], q1, rec.wy[0] * q0)) * iq;
-    wnrm.x = fmaf(rec.n[2].x, q2, fmaf(rec.n[1].x, q1, rec.n[0].x * q0)) * iq;
-    wnrm.y = fmaf(rec.n[2].y, q2, fmaf(rec.n[1].y, q1, rec.n[0].y * q0)) * iq;
-    wnrm.z = fmaf(rec.n[2].z, q2, fmaf(rec.n[1].z, q1, rec.n[0].z * q0)) * iq;
+    wposx = fmaf(bits_f(rec.wx2), q2, fmaf(bits_f(rec.wx1), q1, bits_f(rec.wx0) * q0)) * iq;
+    wposy = fmaf(bits_f(rec.wy2), q2, fmaf(bits_f(rec.wy1), q1, bits_f(rec.wy0) * q0)) * iq;
+    wnrm.x = fmaf(bits_f(rec.n2x), q2, fmaf(bits_f(rec.n1x), q1, bits_f(rec.n0x) * q0)) * iq;
+    wnrm.y = fmaf(bits_f(rec.n2y), q2, fmaf(bits_f(rec.n1y), q1, bits_f(rec.n0y) * q0)) * iq;
+    wnrm.z = fmaf(bits_f(rec.n2z), q2, fmaf(bits_f(rec.n1z), q1, bits_f(rec.n0z) * q0)) * iq;
     return true;
 }
 
