@@ -40,6 +40,20 @@ void emul_srgb_encode_both(const float* x, uint8_t* by_probes, uint8_t* by_lut, 
         by_lut[i] = (uint8_t)srgb_encode_lut(thresh, lut, x[i]);
     }
 }
+// normal_texel_fast against normal_texel over n stencils: returns the number of texels where the fast route claimed a
+// result that differs from the spec's (must be 0); *n_fast = how many it claimed at all
+uint64_t emul_normal_fast_check(const float* xs, const float* ys, const float* h4, size_t n, uint64_t* n_fast) {
+    uint64_t bad = 0, fast = 0;
+    for (size_t i = 0; i < n; ++i) {
+        uint32_t t = 0;
+        if (normal_texel_fast(xs[i], ys[i], h4[4 * i], h4[4 * i + 1], h4[4 * i + 2], h4[4 * i + 3], t)) {
+            ++fast;
+            if (t != normal_texel(xs[i], ys[i], h4[4 * i], h4[4 * i + 1], h4[4 * i + 2], h4[4 * i + 3])) ++bad;
+        }
+    }
+    *n_fast = fast;
+    return bad;
+}
 void emul_sincos(const float* x, float* s, float* c, size_t n) { for (size_t i = 0; i < n; ++i) sincos_f(x[i], s[i], c[i]); }
 
 void emul_normals_interior(const EmulTile* e, int W, int H) {
@@ -242,12 +256,18 @@ int emul_big_item(const int32_t* X, const int32_t* Y, const float* z, uint32_t i
     *was_medium = medium ? 1 : 0;
     for (uint32_t lane = 0; lane < 64; ++lane) {
         if (medium)
-            big_medium_lane(X, Y, z, id, W, H, rx, ry, lane, [&](const uint32_t pix[4], const uint64_t key[4]) {
+            big_medium_lane(X, Y, z, id, W, H, rx, ry, lane, [&](const uint32_t pix[4], const uint64_t key[4], const int32_t py[4]) {
                 for (int k = 0; k < 4; ++k)
-                    if (key[k] != kVisClear) sink(pix[k], key[k]);     // the contract: pix[k] is only meaningful with a key
+                    if (key[k] != kVisClear) {      // the contract: pix[k], py[k] are only meaningful with a key
+                        if (py[k] < 0 || py[k] >= H || (size_t)py[k] != pix[k] / (size_t)W) ++sink.violations;      // the row the kernel marks
+                        sink(pix[k], key[k]);
+                    }
             });
         else
-            big_giant_lane(X, Y, z, id, W, H, rx, ry, lane, [&](size_t pix, uint64_t key) { sink(pix, key); });
+            big_giant_lane(X, Y, z, id, W, H, rx, ry, lane, [&](size_t pix, uint64_t key, int32_t py) {
+                if (py < 0 || py >= H || (size_t)py != pix / (size_t)W) ++sink.violations;
+                sink(pix, key);
+            });
     }
     *n_frag = sink.n;
     return sink.violations;

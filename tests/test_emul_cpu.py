@@ -328,3 +328,44 @@ def test_split_resolve_equals_resolve_varyings(topo, orc):
             assert_same_frame(e.render(), ref, f"one-step route {cfg}")
     finally:
         L.emul_set_split(0)
+
+
+def test_normal_texel_fast_path():
+    """normal_texel_fast (reciprocal square root estimate + guard band, the route k_normals_interior takes for 998 texels
+    in 1000) never claims a texel that differs from normal_texel's: random stencils at the benchmark's metric steps, steep
+    and flat ones, heights that drive a component onto a code boundary (where the guard must hand over), and non-finite
+    heights (which must always be handed over)."""
+    import ctypes as C
+    L = emul.lib()
+    L.emul_normal_fast_check.restype = C.c_uint64
+    L.emul_normal_fast_check.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    rng = np.random.default_rng(21)
+    total_fast = 0
+    for rep in range(6):
+        n = 4_000_000
+        xs = rng.uniform(20.0, 120.0, n).astype(np.float32)          # half-steps in metres (COP90: ~46 x 33 m at 45 degrees)
+        ys = rng.uniform(5.0, 120.0, n).astype(np.float32)
+        scale = np.float32([0.5, 30.0, 300.0, 3000.0, 3.0e5, 1.0e-3][rep])
+        h = (rng.standard_normal((n, 4)) * scale + rng.uniform(0, 4000, (n, 1))).astype(np.float32)
+        if rep == 1:      # adversarial: choose hR so that component x lands (in f64) right on a code boundary
+            k = rng.integers(1, 255, n)
+            nxt = (k - 127.5) / 127.5                                  # n_x with 127.5 n + 128 = k + 0.5... a boundary of floor(t)
+            nxt = (k + rng.choice([-1e-6, 0.0, 1e-6], n) - 128.0) / 127.5
+            # n_x = -2y dz / sqrt((2y dz)^2 + (2x dzy)^2 + (4xy)^2); with dzy = 0: dz = -n_x * 2x / sqrt(1 - n_x^2)
+            dz = -nxt * (2.0 * xs.astype(np.float64)) / np.sqrt(np.maximum(1e-12, 1.0 - nxt * nxt))
+            h[:, 0] = h[:, 3]                                          # hT = hB
+            h[:, 2] = (h[:, 1].astype(np.float64) + dz).astype(np.float32)
+        if rep == 5:
+            h[::7, 0] = np.inf
+            h[3::11, 2] = np.nan
+            h[5::13, 1] = -np.inf
+            h[::17] = 3.0e38
+        nf = C.c_uint64()
+        bad = L.emul_normal_fast_check(emul._p(xs), emul._p(ys), emul._p(np.ascontiguousarray(h)), n, C.byref(nf))
+        assert bad == 0, f"rep {rep}: {bad} texels differ"
+        total_fast += nf.value
+        if rep == 0:
+            assert nf.value > 0.99 * n          # ordinary terrain: the fast route carries almost everything
+        if rep == 1:
+            assert nf.value < 0.8 * n           # on the boundaries the guard hands over
+    assert total_fast > 10_000_000

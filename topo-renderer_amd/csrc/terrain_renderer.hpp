@@ -94,7 +94,7 @@ class TerrainRenderer {
     std::map<GeoKey, Tile> tiles_;
     uint64_t next_seq_ = 1;
     bool table_dirty_ = true;
-    int lds_rows_ = 16;
+    int lds_rows_ = 32;       // LDS tile height of k_normals_interior: 32 rows is the sweep optimum (profiles/r02_normals_lds_sweep.json)
     uint32_t big_cap_cfg_ = 0, rare_cap_cfg_ = 0;
     uint64_t rare_cap_auto_ = 0;           // rare-queue capacity topo_render grew to after an overflow (0 = default)
     uint32_t timing_slots_ = 0x3Fu;        // topo_set_timing_slots: which per-kernel durations to measure

@@ -63,6 +63,13 @@ __device__ __forceinline__ Vis view_vis(const FrameParams& P, uint32_t view) {
     return Vis{P.vis + (size_t)view * P.W * P.H, P.vis, P.dirty};
 #endif
 }
+// the atomic alone, for callers that mark the segments themselves (k_raster_big: once per item and pixel row)
+__device__ __forceinline__ void vis_min_unmarked(const Vis& v, size_t pix, uint64_t key) {
+#ifdef TOPO_BOUNDS_CHECK
+    if (!TOPO_CHK(v.counters, pix < v.view_keys, 2u, pix)) return;
+#endif
+    atomicMin(reinterpret_cast<unsigned long long*>(v.p + pix), (unsigned long long)key);
+}
 __device__ __forceinline__ void vis_min(const Vis& v, size_t pix, uint64_t key) {
 #ifdef TOPO_BOUNDS_CHECK
     if (!TOPO_CHK(v.counters, pix < v.view_keys, 2u, pix)) return;
@@ -160,42 +167,66 @@ __global__ __launch_bounds__(64) void k_block_minmax(TileDev t, uint32_t w, uint
     }
 }
 
-// Interior normals (compute_normals_shader.wgsl:22-51) of a batch of tiles (blockIdx.z).  64 x ROWS output
-// texels per 256-thread workgroup; the (ROWS+2) x 66 height tile is staged in LDS with coalesced row loads,
-// each texel's four taps then come from LDS; cos(latitude) is evaluated once per row.  The border ring, which
-// the shader leaves untouched (:30-33) and which is zero in a freshly created texture, is written as zero here
-// so no separate clear is needed; seam/corner passes run afterwards.  ROWS is the LDS tile-size knob.
+// Interior normals (compute_normals_shader.wgsl:22-51) of a batch of tiles (blockIdx.z).  64 x ROWS output texels per
+// 256-thread workgroup; the (ROWS+2) x 66 height tile is staged in LDS row by row -- wave w takes rows w, w + 4, ...: one
+// coalesced 256-byte read per row plus a two-lane read for the right halo -- each texel's four taps then come from LDS;
+// cos(latitude) is evaluated once per row.  The border ring, which the shader leaves untouched (:30-33) and which is
+// zero in a freshly created texture, is written as zero here so no separate clear is needed; seam/corner passes run
+// afterwards.  ROWS is the LDS tile-size knob (topo_set_normals_lds_rows).
+// Arithmetic: normal_texel_fast() -- a reciprocal-square-root estimate and a guard band around the 8-bit code boundaries
+// -- settles 998 texels in 1000; a wave in which some lane's texel falls inside the guard band (or is not finite)
+// evaluates the full chain (correctly rounded sqrt, three IEEE divisions) for those lanes.  Same bytes either way.
 template <int ROWS>
 __global__ __launch_bounds__(256) void k_normals_interior(const TileDev* __restrict__ tiles, uint32_t first, int W, int H) {
-    __shared__ float tile[ROWS + 2][66];
+    __shared__ float tile[ROWS + 2][68];      // 66 used; the row pitch keeps rows 16-byte aligned
     __shared__ float s_ys[ROWS];
     const TileDev& t = tiles[first + blockIdx.z];
     const auto heights = TOPO_GLOBAL_F32(t.heights);          // global, not flat, memory operations
     const auto normals = TOPO_GLOBAL_U32_RW(t.normals);
     const int x0 = blockIdx.x * 64, y0 = blockIdx.y * ROWS;
-    for (int idx = threadIdx.x; idx < (ROWS + 2) * 66; idx += 256) {
-        const int ly = idx / 66, lx = idx - ly * 66;
-        const int gx = x0 + lx - 1, gy = y0 + ly - 1;
-        float v = 0.0f;
-        if (gx >= 0 && gx < W && gy >= 0 && gy < H) v = heights[(size_t)gy * W + gx];
-        tile[ly][lx] = v;
+    const int tx = threadIdx.x & 63, wy = threadIdx.x >> 6;
+    {
+        // columns -1..62 by all lanes, 63 and 64 by lanes 0 and 1.  Every load is unconditional (clamped address, value
+        // discarded where it does not apply) and all of a wave's loads are issued before the first LDS write: a branch
+        // around a load makes the compiler wait for it before going on, one trip to memory per row.
+        constexpr int kIter = (ROWS + 2 + 3) / 4;
+        const int gx = x0 + tx - 1, gx2 = x0 + 63 + (tx & 1);
+        const int cx = gx < 0 ? 0 : (gx > W - 1 ? W - 1 : gx), cx2 = gx2 > W - 1 ? W - 1 : gx2;
+        float a[kIter], b[kIter];
+#pragma unroll
+        for (int k = 0; k < kIter; ++k) {
+            const int gy = y0 + wy + 4 * k - 1;
+            const int cy = gy < 0 ? 0 : (gy > H - 1 ? H - 1 : gy);
+            a[k] = heights[(size_t)cy * W + cx];
+            b[k] = heights[(size_t)cy * W + cx2];
+        }
+#pragma unroll
+        for (int k = 0; k < kIter; ++k) {
+            const int ly = wy + 4 * k, gy = y0 + ly - 1;
+            const bool row_in = gy >= 0 && gy < H;
+            if (ly < ROWS + 2) {
+                tile[ly][tx] = row_in && gx >= 0 && gx < W ? a[k] : 0.0f;
+                if (tx < 2) tile[ly][64 + tx] = row_in && gx2 < W ? b[k] : 0.0f;
+            }
+        }
     }
     if (threadIdx.x < ROWS) {
         const float latitude = ((float)(y0 + (int)threadIdx.x) - t.raster_y) * -t.scale_y + t.model_y;
         s_ys[threadIdx.x] = deg2rad(t.scale_y) * kR0 * cos_f(deg2rad(latitude));
     }
     __syncthreads();
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int gx = x0 + tx;
     const float xs = deg2rad(t.scale_x) * kR0;
 #pragma unroll
-    for (int r = ty; r < ROWS; r += 4) {
+    for (int r = wy; r < ROWS; r += 4) {
         const int gy = y0 + r;
-        if (gx >= W || gy >= H) continue;
+        if (gy >= H) break;      // (wave-uniform)
+        const bool interior = gx >= 1 && gy >= 1 && gx < W - 1 && gy < H - 1;
+        const float hT = tile[r][tx + 1], hL = tile[r + 1][tx], hR = tile[r + 1][tx + 2], hB = tile[r + 2][tx + 1], ys = s_ys[r];
         uint32_t texel = 0;
-        if (gx >= 1 && gy >= 1 && gx < W - 1 && gy < H - 1)
-            texel = normal_texel(xs, s_ys[r], tile[r][tx + 1], tile[r + 1][tx], tile[r + 1][tx + 2], tile[r + 2][tx + 1]);
-        normals[(size_t)gy * W + gx] = texel;
+        const bool settled = normal_texel_fast(xs, ys, hT, hL, hR, hB, texel) || !interior;
+        if (!settled) texel = normal_texel(xs, ys, hT, hL, hR, hB);      // the guard band and non-finite heights: the full chain
+        if (gx < W) normals[(size_t)gy * W + gx] = interior ? texel : 0u;
     }
 }
 
@@ -798,10 +829,15 @@ __device__ __forceinline__ float unif(float v) { return __uint_as_float((uint32_
 // (big_giant_lane); both are in topo_pipeline.h and run lane by lane on the CPU in the tests.  Fragments are issued
 // blind (no depth pre-test, see vis_min): only entries that carry a fragment (key != kVisClear) are dereferenced.
 __global__ __launch_bounds__(256) void k_raster_big(FrameParams P) {
+    // Segment marks: an item stays inside one 64 x 64 px region, i.e. inside 64 pixel rows of one or two 64-key segments
+    // each.  Instead of one mark store beside every atomic instruction (half of this kernel's memory instructions), the
+    // lanes note the rows they hit in LDS and lane r marks row r's segment(s) once per item.
+    __shared__ uint8_t s_rows[4][64];
     uint32_t count = P.counters[1];
     if (count > P.big_cap) count = P.big_cap;
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t wave_global = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wave_count = gridDim.x * 4;
+    const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    s_rows[wave][lane] = 0;
+    const uint32_t wave_global = blockIdx.x * 4 + wave, wave_count = gridDim.x * 4;
     for (uint32_t item = P.counters[6] + wave_global; item < count; item += wave_count) {
         // The item is the same for the whole wave, but the compiler cannot use scalar loads for it (the queue is
         // written by other kernels through the same pointer type): say so field by field, and the integer setup
@@ -817,14 +853,32 @@ __global__ __launch_bounds__(256) void k_raster_big(FrameParams P) {
         const Vis vis = view_vis(P, bi.view);
         const int32_t rx = (int32_t)(bi.region & 0xFFFFu), ry = (int32_t)(bi.region >> 16);
         if (!TOPO_CHK(P.counters, bi.view < P.n_views && rx * 64 < P.W && ry * 64 < P.H, 11u, bi.region)) continue;
+        uint8_t* const rows = s_rows[wave];
         if (spans_fit_int32(bi.X[0], bi.Y[0], bi.X[1], bi.Y[1], bi.X[2], bi.Y[2])) {
-            big_medium_lane(bi.X, bi.Y, bi.z, bi.id, P.W, P.H, rx, ry, lane, [&](const uint32_t pix[4], const uint64_t key[4]) {
+            big_medium_lane(bi.X, bi.Y, bi.z, bi.id, P.W, P.H, rx, ry, lane, [&](const uint32_t pix[4], const uint64_t key[4], const int32_t py[4]) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    if (key[k] != kVisClear) vis_min(vis, pix[k], key[k]);
+                    if (key[k] != kVisClear) {
+                        vis_min_unmarked(vis, pix[k], key[k]);
+                        rows[py[k] & 63] = 1;
+                    }
             });
         } else {
-            big_giant_lane(bi.X, bi.Y, bi.z, bi.id, P.W, P.H, rx, ry, lane, [&](size_t pix, uint64_t key) { vis_min(vis, pix, key); });
+            big_giant_lane(bi.X, bi.Y, bi.z, bi.id, P.W, P.H, rx, ry, lane, [&](size_t pix, uint64_t key, int32_t py) {
+                vis_min_unmarked(vis, pix, key);
+                rows[py & 63] = 1;
+            });
+        }
+        // (LDS operations of one wave complete in order: the notes above are visible to the reads below)
+        if (rows[lane]) {
+            rows[lane] = 0;
+            const int32_t y = ry * 64 + (int32_t)lane, x0 = rx * 64, x1 = min(rx * 64 + 63, P.W - 1);
+            const size_t first = (size_t)(vis.p - vis.base) + (size_t)y * P.W;
+            const size_t s0 = (first + x0) >> 6, s1 = (first + x1) >> 6;      // a region row lies in one segment, two when W or the view origin is not a multiple of 64
+            if (TOPO_CHK(P.counters, y < P.H && s1 < (((size_t)P.n_views * P.W * P.H + 63) >> 6), 14u, s1)) {
+                vis.dirty[s0] = 1;
+                if (s1 != s0) vis.dirty[s1] = 1;
+            }
         }
     }
 }
@@ -1311,9 +1365,9 @@ void launch_normals_interior(const TileDev* tiles, uint32_t first, uint32_t coun
     switch (lds_rows) {
         case 4: TOPO_K1(4); break;
         case 8: TOPO_K1(8); break;
-        case 32: TOPO_K1(32); break;
+        case 16: TOPO_K1(16); break;
         case 64: TOPO_K1(64); break;
-        default: TOPO_K1(16); break;
+        default: TOPO_K1(32); break;
     }
 #undef TOPO_K1
 }

@@ -280,6 +280,35 @@ TOPO_HD uint32_t normal_texel(float x, float y, float hT, float hL, float hR, fl
     return to_unorm8(n.x) | (to_unorm8(n.y) << 8) | (to_unorm8(n.z) << 16) | (to_unorm8(0.0f) << 24);
 }
 
+// The same texel by a shorter route, when that route can be trusted.  The texel is three 8-bit codes floor(t_i) with
+// t_i = 255 * 0.5 (n_i + 1) + 0.5 = 127.5 n_i + 128, n = v / |v|.  normal_texel() reaches t_i through a correctly rounded
+// sqrt, three IEEE divisions and four more roundings: |t_spec - T_i| <= 4.6e-5 for the real-number value T_i (n: 3 ulp of
+// relative error = 1.8e-7, n + 1: 6e-8, x 127.5 = 3.1e-5; the two roundings near 255: 7.6e-6 each).  The short route --
+// one reciprocal square root estimate (v_rsq_f32, 1 ulp), three products, one fma each -- has |t' - T_i| <= 3.8e-5
+// (n': 2.4e-7 relative, x 127.5; fma: 7.6e-6).  So whenever the fractional part of t' is at least kNormalGuard = 2e-4
+// away from 0 and from 1, floor(t') = floor(t_spec) -- the two differ by at most 8.4e-5 -- and the texel is known
+// without the divisions; otherwise (1.2 texels in a thousand, and any non-finite input) the caller evaluates
+// normal_texel().  Exhaustive-by-sampling check of exactly this claim: tests/test_emul_cpu.py::test_normal_texel_fast_path.
+constexpr float kNormalGuard = 2.0e-4f;
+TOPO_HD bool normal_texel_fast(float x, float y, float hT, float hL, float hR, float hB, uint32_t& texel) {
+    const float dxx = x - (-x), dyy = y - (-y), dxz = hR - hL, dyz = hT - hB;      // the same differences normal_texel forms
+    const float vx = -(dxz * dyy), vy = -(dxx * dyz), vz = dxx * dyy;
+    const float ss = (vx * vx + vy * vy) + vz * vz;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float r = __builtin_amdgcn_rsqf(ss);
+#else
+    const float r = 1.0f / sqrtf(ss);          // (test builds: also within 1 ulp of the reciprocal square root)
+#endif
+    const float tx = fmaf(vx * r, 127.5f, 128.0f), ty = fmaf(vy * r, 127.5f, 128.0f), tz = fmaf(vz * r, 127.5f, 128.0f);
+    const float fx = floorf(tx), fy = floorf(ty), fz = floorf(tz);
+    const float gx = tx - fx, gy = ty - fy, gz = tz - fz;      // exact: t in [0, 256)
+    // every comparison is false for a NaN, so a non-finite intermediate fails the test
+    const bool ok = gx >= kNormalGuard && gx <= 1.0f - kNormalGuard && gy >= kNormalGuard && gy <= 1.0f - kNormalGuard &&
+                    gz >= kNormalGuard && gz <= 1.0f - kNormalGuard && tx < 256.0f && ty < 256.0f && tz < 256.0f && tx >= 0.0f && ty >= 0.0f && tz >= 0.0f;
+    texel = (uint32_t)fx | ((uint32_t)fy << 8) | ((uint32_t)fz << 16);      // alpha: to_unorm8(0) = 0
+    return ok;
+}
+
 // ---- fragment shading (render_shader.wgsl:75-115) ------------------------------------------------
 TOPO_HD float hash12n(float sx, float sy) {
     float px = fract_f(sx * 5.3987f);

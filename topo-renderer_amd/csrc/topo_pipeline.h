@@ -309,8 +309,8 @@ TOPO_HD void raster_rows(int32_t W, int32_t H, int32_t X0, int32_t Y0, int32_t X
 
 // k_raster_big, medium triangles (spans_fit_int32): the part of the triangle's pixel box inside region (rx, ry)
 // (64 px units) is tiled row-major by the wave's 64 lanes, the row length rounded up to 8/16/32/64; lane `lane`
-// visits the pixels (px0 + u, py0 + v0 + k*rows) and hands them over four at a time: emit4(pix[4], key[4]).
-// CONTRACT: an entry with key == kVisClear carries no fragment and its pix[] is NOT a valid index (lanes beyond
+// visits the pixels (px0 + u, py0 + v0 + k*rows) and hands them over four at a time: emit4(pix[4], key[4], py[4]).
+// CONTRACT: an entry with key == kVisClear carries no fragment and its pix[] / py[] are NOT valid (lanes beyond
 // the box keep stepping their pixel counter) -- a sink must not touch pix[k] without testing key[k].
 template <typename Emit4>
 TOPO_HD void big_medium_lane(const int32_t X[3], const int32_t Y[3], const float zv[3], uint32_t id, int32_t W, int32_t H,
@@ -350,13 +350,16 @@ TOPO_HD void big_medium_lane(const int32_t X[3], const int32_t Y[3], const float
     uint32_t pixel = (uint32_t)((py0 + v0) * W + px0 + u);
     const uint32_t pstep = (uint32_t)(rows * W);
     const bool ucol = u < bw;
+    int32_t yrow = py0 + v0;
     for (int32_t vb = 0; vb < bh; vb += 4 * rows) {
         uint32_t pix[4];
         uint64_t key[4];
+        int32_t pyk[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             key[k] = kVisClear;
             pix[k] = pixel;
+            pyk[k] = yrow;
             if (ucol && vb + k * rows + v0 < bh && (F0 | F1 | F2) >= 0) {
                 const float w1 = (float)(F1 - b1) * iA, w2 = (float)(F2 - b2) * iA;
                 float z = fmaf(w1, dz1, fmaf(w2, dz2, z0));
@@ -367,14 +370,15 @@ TOPO_HD void big_medium_lane(const int32_t X[3], const int32_t Y[3], const float
             }
             F0 -= S0; F1 -= S1; F2 -= S2;
             pixel += pstep;
+            yrow += rows;
         }
-        emit4(pix, key);
+        emit4(pix, key, pyk);
     }
 }
 
 // k_raster_big, giants (a vertex pair >= 64 px apart): the 64-bit edge functions of triangle_setup, evaluated once per
 // lane at its pixel of the first 8x8 sub-chunk of region (rx, ry) and then stepped (8 px in x: + 2048 dy, 8 px in y:
-// - 2048 dx), so a sub-chunk costs three 64-bit additions instead of six 64-bit multiplications.  emit(pixel index, key).
+// - 2048 dx), so a sub-chunk costs three 64-bit additions instead of six 64-bit multiplications.  emit(pixel index, key, py).
 template <typename Emit>
 TOPO_HD void big_giant_lane(const int32_t X[3], const int32_t Y[3], const float zv[3], uint32_t id, int32_t W, int32_t H,
                             int32_t rx, int32_t ry, uint32_t lane, Emit&& emit) {
@@ -417,7 +421,7 @@ TOPO_HD void big_giant_lane(const int32_t X[3], const int32_t Y[3], const float 
                 float z = fmaf(f1 * ts.iA, ts.dz1, fmaf(f2 * ts.iA, ts.dz2, ts.z0));
                 if (z < 1.0f) {
                     if (z < 0.0f) z = 0.0f;
-                    emit((size_t)py * W + px, vis_key(z, id));
+                    emit((size_t)py * W + px, vis_key(z, id), py);
                 }
             }
             F0 += ax0; F1 += ax1; F2 += ax2;
