@@ -59,7 +59,12 @@ def main():
                     help="after the timed region, also time the same panoramas with 2 frames in flight (reported under \"pipelined\")")
     ap.add_argument("--pitch", type=float, default=0.0, help="camera pitch in radians (reference: positive looks down)")
     ap.add_argument("--host-path", action="store_true", help="also time topo_render (host outputs, PCIe-inclusive)")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="skip the rocprofv3 --pmc child passes (FETCH_SIZE, WRITE_SIZE, SQ counters) behind roofline.traffic / roofline_valu")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)      # this process IS such a pass: a few frames, no JSON
     args = ap.parse_args()
+    if args.pmc_child:
+        args.no_cpu_baseline = args.no_pmc = True
 
     import numpy as np
     import torch
@@ -122,32 +127,41 @@ def main():
         load_ms.append(r.timings()["load"])
     load_ms = min(load_ms)
 
-    # ---- outputs: slot-major strip (panorama.py): strip[c][r] = sector r*per + c, so the all-gather of slot c is one
-    # contiguous block and can run while slot c+1 is being rendered
+    # ---- outputs: the sector-major strip of the C ABI (topo_render_panorama): strip[8][PH][SW][4], rank g's sectors
+    # [8g/N, 8(g+1)/N) one contiguous block.  A rank renders ALL its sectors in one submission (one set of kernel launches:
+    # a single view fills the chip worse) and the strip is assembled by ONE in-place all-gather, ordered after the frame
+    # by the stream: the renderer runs on torch's current stream (set_stream above) and the collective waits for that stream.
     per = N_SECTORS // world
     my = list(T.panorama.sector_range(rank, world))
+    if world > 1:
+        depth_frames = 1            # frames in flight run on the contexts' own streams, which the collective would not wait for
+    use_capi_comm = world > 1 and os.environ.get("TOPO_BENCH_COMM", "torch") == "capi"
+    comm = None
+    if use_capi_comm:
+        # the collective behind the C ABI (RCCL bound by libtopo_hip.so itself): the unique id travels over torch.distributed
+        uid = torch.from_numpy(T.comm_unique_id() if rank == 0 else np.zeros(128, np.uint8)).cuda()
+        dist.broadcast(uid, 0)
+        comm = T.Comm(rank, world, uid.cpu().numpy(), device=local_rank)
     # one output set per frame in flight
     r.set_pipeline_depth(depth_frames)
-    outs = [(torch.empty(T.panorama.strip_shape(world, PH, SW), dtype=torch.uint8, device="cuda"),
-             torch.empty((per, PH, SW), dtype=torch.float32, device="cuda")) for _ in range(depth_frames)]
-    strip, depth = outs[0]
+    outs = [(torch.empty((N_SECTORS, PH, SW, 4), dtype=torch.uint8, device="cuda"),
+             torch.empty((N_SECTORS, PH, SW), dtype=torch.float32, device="cuda")) for _ in range(depth_frames)]
+    strip, depth_all = outs[0]
+    depth = depth_all[my[0]:my[0] + per]
     frame_no = [0]
 
     def step():
-        nonlocal strip, depth
-        if world == 1:
-            # one submission for all 8 sectors: strip[c][0] are contiguous
-            strip, depth = outs[frame_no[0] % depth_frames]
-            frame_no[0] += 1
-            r.render_views_device(views, SW, PH, strip.data_ptr(), PH * SW * 4, SW * 4, depth.data_ptr(), PH * SW * 4, SW * 4)
+        nonlocal strip, depth, depth_all
+        strip, depth_all = outs[frame_no[0] % depth_frames]
+        depth = depth_all[my[0]:my[0] + per]
+        frame_no[0] += 1
+        if use_capi_comm:
+            r.render_panorama(comm, eye, 0.0, SW, PH, vlon, vlat, strip.data_ptr(), 0, args.view_mode, args.pitch)
             return
-        works = []
-        for c in range(per):
-            r.render_views_device([views[my[c]]], SW, PH, strip[c, rank].data_ptr(), PH * SW * 4, SW * 4,
-                                  depth[c].data_ptr(), PH * SW * 4, SW * 4)
-            works.append(T.panorama.gather_slot(dist, strip, c, rank, world, async_op=True))
-        for w in works:
-            w.wait()
+        r.render_views_device([views[k] for k in my], SW, PH, strip[my[0]].data_ptr(), PH * SW * 4, SW * 4,
+                              depth.data_ptr(), PH * SW * 4, SW * 4)
+        if world > 1:
+            T.panorama.gather_sector_major(dist, strip, rank, world)      # RGBA only: the depth stays with its rank
 
     def fence():
         r.join()
@@ -168,7 +182,7 @@ def main():
         step()
         tm = r.timings()
         if tm["total"] > 0.0:
-            samples.append({k: tm[k] * (per if world > 1 else 1) for k in KERNELS + ("total",)})
+            samples.append({k: tm[k] for k in KERNELS + ("total",)})
     fence()
     n_detail = len(samples)
     detail = {k: (sorted(smp[k] for smp in samples)[n_detail // 2] if n_detail else 0.0) for k in KERNELS + ("total",)}   # medians
@@ -177,6 +191,11 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    if args.pmc_child:              # a rocprofv3 --pmc pass of this command: the frames above and a few more are all it needs
+        for _ in range(3):
+            step()
+        fence()
+        return
     kernel_ms = {k: 0.0 for k in (dom, "total")}
     timed_frames = 0
     t_start = time.perf_counter()
@@ -185,11 +204,11 @@ def main():
         # HIP-event durations of a step's kernels (the events sit on the stream the kernels are launched on).  One frame in
         # flight: this step's (reading them waits for it, which the next submission's host-side staging does anyway);
         # pipelined: those of the oldest frame in flight, so that reading them does not drain the pipeline
-        tm = r.timings()                 # N > 1: the last sector submission of the step
+        tm = r.timings()
         if tm["total"] > 0.0:
             timed_frames += 1
             for k in kernel_ms:
-                kernel_ms[k] += tm[k] * (per if world > 1 else 1)
+                kernel_ms[k] += tm[k]
     fence()
     elapsed = time.perf_counter() - t_start
     if dist is not None:
@@ -214,32 +233,48 @@ def main():
     #   k_raster  : 4 B per DEM texel of the mosaic share this rank is responsible for ("DEM read" = 4*T*W*H / N) --
     #               since the occlusion filter most of those texels are ruled out from the 8-byte-per-block min/max
     #               table instead of being read, so this prices the stage, not the bytes the kernel touches.
+    #
+    # SURVEY.md 8(d) prices the path by what the REFERENCE's data flow needs, not by this design's intermediates:
+    #   resolve stage  : "write 4*P RGBA + 4*P depth" = 8 B per pixel  (the 8 B visibility key this design also reads is its own)
+    #   whole frame    : "read 4*T*W*H (DEM once) + write 8*P"
+    # `roofline.achieved` / `frac` use those 8(d) bytes; the line keeps the design's own count (16 B per pixel incl. the key)
+    # as `design_bytes_per_launch` / `frac_design_bytes`.
     my_pixels = per * SW * PH
-    alg = {"resolve": ("k_resolve", 16.0 * my_pixels),
-           "raster": ("k_raster", 4.0 * n_tiles * TILE * TILE / world),
-           "raster_big": ("k_raster_rare+k_raster_big", 8.0 * my_pixels)}
-    dom_name, dom_bytes = alg[dom]
+    alg = {"resolve": ("k_resolve", 8.0 * my_pixels, 16.0 * my_pixels),
+           "raster": ("k_raster", 4.0 * n_tiles * TILE * TILE / world, 4.0 * n_tiles * TILE * TILE / world),
+           "raster_big": ("k_raster_rare+k_raster_big", 8.0 * my_pixels, 8.0 * my_pixels)}
+    dom_name, dom_bytes, dom_design = alg[dom]
     dom_s = kernel_ms[dom] / 1e3
     achieved = dom_bytes / dom_s / 1e9 if dom_s > 0 else 0.0
+    frame_bytes_8d = 4.0 * n_tiles * TILE * TILE / world + 8.0 * my_pixels
     roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
-                "algorithmic_bytes_per_launch": dom_bytes, "avg_launch_ms": round(kernel_ms[dom], 4)}
-    # HBM bytes per launch from the PMC counters cannot be collected from inside this process; they are measured in
-    # separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this same command
-    # (tools/collect_hbm_pmc.sh) and read back from profiles/hbm_traffic.json when it matches the workload.
-    try:
-        with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
-            tr = json.load(f)
-        ent = tr.get("kernels", {}).get(dom_name.split("+")[-1])
-        if tr.get("workload") == args.workload and tr.get("n_gpus") == world and ent:
-            roofline["traffic"] = ent["bytes_per_launch"]
-            roofline["traffic_source"] = tr.get("source")
-    except (OSError, ValueError, KeyError):
-        pass
+                "algorithmic_bytes_8d": dom_bytes, "avg_launch_ms": round(kernel_ms[dom], 4),
+                "algorithmic_bytes_what": "SURVEY 8(d): 4 B RGBA8 + 4 B depth written per pixel of this rank's sectors" if dom == "resolve" else "SURVEY 8(d)",
+                "design_bytes_per_launch": dom_design,
+                "frac_design_bytes": round(dom_design / dom_s / 1e9 / HBM_PEAK_GBPS, 5) if dom_s > 0 else None,
+                "frame_algorithmic_bytes_8d": frame_bytes_8d,
+                "frame_frac_8d": round(frame_bytes_8d / (ms_per_step / 1e3) / 1e9 / HBM_PEAK_GBPS, 5)}
+    # HBM bytes per launch and the SQ instruction counters cannot be read from inside this process: they come from separate
+    # `rocprofv3 --kernel-trace --pmc <counter>` passes of THIS command, run as child processes right here (rank 0, N = 1),
+    # one counter group per pass as MI355X_MICROARCH.md prescribes.  FETCH_SIZE is corrected by the factor calibrated for
+    # this access width (profiles/r02_calibration.json: 2.0 for 4- and 8-byte-per-lane reads on gfx950; raw value kept).
+    roofline_valu = None
+    if rank == 0 and world == 1 and not args.no_pmc:
+        pmc = collect_pmc(args, dom_name.split("+")[-1])
+        if pmc.get("FETCH_SIZE") is not None and pmc.get("WRITE_SIZE") is not None:
+            fetch_factor = 2.0
+            roofline["traffic"] = round(pmc["FETCH_SIZE"] * fetch_factor + pmc["WRITE_SIZE"])
+            roofline["traffic_detail"] = {"FETCH_SIZE_raw": round(pmc["FETCH_SIZE"]), "fetch_correction": fetch_factor,
+                                          "WRITE_SIZE": round(pmc["WRITE_SIZE"]), "launches_averaged": pmc.get("launches"),
+                                          "source": "rocprofv3 --kernel-trace --pmc passes of this command, run by this process as children"}
+        else:
+            roofline["traffic_note"] = pmc.get("error", "PMC passes unavailable")
+        roofline_valu = valu_roofline(pmc, kernel_ms[dom])
     dem_bytes = 4.0 * n_tiles * TILE * TILE / world
     stage_ms = kernel_ms["cull"] + kernel_ms["raster"] + kernel_ms["occlusion"] + kernel_ms["raster_big"]
     per_kernel = {name: {"ms": round(kernel_ms[k], 4), "algorithmic_GBps": round(b / (kernel_ms[k] / 1e3) / 1e9, 1) if kernel_ms[k] > 0 else None}
-                  for k, (name, b) in alg.items()}
+                  for k, (name, b, _design) in alg.items()}
     per_kernel["dem_to_visibility_stage"] = {"ms": round(stage_ms, 4), "what": "cull + raster + occlusion + rare + big against the DEM read (4*T*W*H/N)",
                                              "algorithmic_GBps": round(dem_bytes / (stage_ms / 1e3) / 1e9, 1) if stage_ms > 0 else None}
 
@@ -259,8 +294,11 @@ def main():
         "config": {"workload": f"{args.workload}: {deg}x{deg} deg COP90-shaped mosaic ({n_tiles} tiles of 1200x1200 f32), "
                                f"{PW}x{PH} panorama = 8 sectors of {SW}x{PH}, view_mode {args.view_mode}",
                    "frames_in_flight": depth_frames,
-                   "sharding": f"azimuth sectors, {per} per GPU, DEM replicated" + (", RCCL all-gather of RGBA per sector slot, pipelined with rendering" if world > 1 else "")},
+                   "sharding": f"azimuth sectors, {per} per GPU in one submission, DEM replicated" +
+                               (", one in-place RCCL all-gather of the sector-major RGBA strip per panorama" +
+                                (" through the C ABI (topo_render_panorama)" if use_capi_comm else " (torch.distributed)") if world > 1 else "")},
         "roofline": roofline,
+        "roofline_valu": roofline_valu,
         "per_kernel": per_kernel,
         "kernel_ms": {k: round(v, 4) for k, v in kernel_ms.items()},
         "kernel_ms_note": f"'{dom}' and 'total': HIP events in the timed region (only those events are recorded there); the other "
@@ -270,6 +308,7 @@ def main():
         "hbm_read_roofline_frac_frame": round((4.0 * n_tiles * TILE * TILE / (ms_per_step / 1e3) / 1e9) / HBM_PEAK_GBPS, 5),
         "counters": counters,
         "terrain_pixel_frac": round(float((depth < 1.0).float().mean().item()), 4),   # this rank's sectors
+        "host_cores": os.cpu_count(),
         "setup_s": round(setup_s, 1),
         "upload_s": round(upload_s, 2),
     }
@@ -314,13 +353,75 @@ def main():
                                                 f"pad_256-pitched depth into pageable memory"}
 
     if args.check and rank == 0:
-        mine = torch.stack([T.panorama.sector(strip, k) for k in my])
+        mine = strip[my[0]:my[0] + per]
         out["check"] = check_against_oracle(T, np, locs, views, my, mine, depth, SW, PH)
 
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+# issue cost of the VALU instruction classes, ns per wave64 instruction per SIMD at full occupancy: measured by
+# tools/calib.hip (profiles/r02_calibration.json, HIP-event wall clock): full-rate f32 fma/mul/add, integer add, moves,
+# logic 1.0-1.2; conversions, comparisons/selects, min/max/med3, floor/fract, shifts, 24/32-bit integer multiplies, 64-bit
+# adds 1.7-1.9; rcp/sqrt/rsq 3.4-3.5
+VALU_NS = {"full": 1.12, "half": 1.78, "trans": 3.45}
+
+
+def valu_roofline(pmc, kernel_ms):
+    """VALU issue time of the dominant kernel's instruction mix (SQ counters of a --pmc pass) over its duration x 1024 SIMDs."""
+    need = ("SQ_INSTS_VALU", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_INT64", "SQ_INSTS_VALU_CVT",
+            "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_ADD_F32")
+    if any(pmc.get(k) is None for k in need) or kernel_ms <= 0:
+        return {"note": pmc.get("error", "SQ counter pass unavailable")}
+    total, trans = pmc["SQ_INSTS_VALU"], pmc["SQ_INSTS_VALU_TRANS_F32"]
+    f32 = pmc["SQ_INSTS_VALU_FMA_F32"] + pmc["SQ_INSTS_VALU_MUL_F32"] + pmc["SQ_INSTS_VALU_ADD_F32"]
+    half = pmc["SQ_INSTS_VALU_INT64"] + pmc["SQ_INSTS_VALU_CVT"] + 0.5 * pmc["SQ_INSTS_VALU_INT32"]      # (INT32 = adds and multiplies/shifts: priced half and half)
+    other = max(0.0, total - trans - f32 - pmc["SQ_INSTS_VALU_INT32"] - pmc["SQ_INSTS_VALU_INT64"] - pmc["SQ_INSTS_VALU_CVT"])
+    full = f32 + 0.5 * pmc["SQ_INSTS_VALU_INT32"] + 0.5 * other      # (other = moves/logic at full rate, compares/selects/min/max at half: split)
+    half += 0.5 * other
+    issue_ns = full * VALU_NS["full"] + half * VALU_NS["half"] + trans * VALU_NS["trans"]
+    return {"kernel_ms": round(kernel_ms, 4), "valu_insts_per_launch": round(total), "class_split": {"full_rate": round(full), "half_rate": round(half), "transcendental": round(trans)},
+            "issue_ns_per_wave_inst": VALU_NS, "valu_issue_ms": round(issue_ns / 1024 / 1e6, 4),
+            "frac": round(issue_ns / 1024 / 1e6 / kernel_ms, 4),
+            "what": "sum over instruction classes of (wave-instructions x issue cost) / (1024 SIMDs x kernel duration); costs from tools/calib.hip"}
+
+
+def collect_pmc(args, kernel):
+    """Per-launch medians of the --pmc counters of `kernel`, from rocprofv3 child passes of this very command."""
+    import csv, glob, shutil, subprocess, tempfile
+    if shutil.which("rocprofv3") is None:
+        return {"error": "rocprofv3 not on PATH"}
+    groups = ["FETCH_SIZE", "WRITE_SIZE",
+              "SQ_INSTS_VALU SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32"]
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="topo_pmc_")
+    try:
+        for gi, grp in enumerate(groups):
+            d = os.path.join(tmp, str(gi))
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc", *grp.split(), "--output-format", "csv", "-d", d, "-o", "p", "--",
+                   sys.executable, os.path.abspath(__file__), "--pmc-child", "--workload", args.workload, "--view-mode", str(args.view_mode),
+                   "--warmup", "1", "--steps", "1"]
+            if args.occlusion_split is not None:
+                cmd += ["--occlusion-split", str(args.occlusion_split)]
+            try:
+                subprocess.run(cmd, cwd=tmp, env=dict(os.environ, TMPDIR=tmp), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
+            except (subprocess.SubprocessError, OSError) as e:
+                out["error"] = f"rocprofv3 --pmc {grp.split()[0]}... failed: {type(e).__name__}"
+                continue
+            vals = {}
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if kernel + "(" in row["Kernel_Name"] or row["Kernel_Name"].rstrip().endswith(kernel):
+                        vals.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+            for c, v in vals.items():
+                v.sort()
+                out[c] = v[len(v) // 2] * (1024.0 if c in ("FETCH_SIZE", "WRITE_SIZE") else 1.0)      # the two sizes are reported in KiB
+                out["launches"] = len(v)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return out
 
 
 def _splitmix64(x):
@@ -352,25 +453,22 @@ def bench_batch(args, T, np, torch, dist, r, locs, deg, SW, PH, rank, world, set
         vps.append((T.geometry_transform(ground + 50.0, lon, lat), yaw, lon, lat))
     per = C5_VIEWPOINTS // world
     mine = vps[rank * per:(rank + 1) * per]
-    # throughput mode: the viewpoints are independent, so (a) C5_GROUP of them go into one submission (8 x 8 sectors = 64 views:
-    # one set of kernel launches instead of eight) and (b) several submissions are kept in flight (one output set each)
-    sets = []
-    for g in range(0, len(mine), C5_GROUP):
-        vs = []
-        for (e, yaw, lon, lat) in mine[g:g + C5_GROUP]:
-            vs += T.panorama_uniforms(e, yaw, SW, PH, lon, lat, args.view_mode)
-        sets.append(np.ascontiguousarray(np.stack([np.ascontiguousarray(u).view(np.uint8).reshape(160) for u in vs])))
+    # throughput mode through the C ABI's batch entry (topo_render_batch): the viewpoints are independent, so 8 of them
+    # (x 8 sectors = 64 views) go into one submission -- one set of kernel launches instead of eight -- and several
+    # submissions are kept in flight (topo_set_pipeline_depth); outputs are written chunk after chunk into the same buffers
     in_flight = args.pipeline if args.pipeline is not None else 2
     r.set_pipeline_depth(in_flight)
     r.set_timing_slots(())               # no per-kernel timing events (each one idles the GPU a few microseconds)
-    nv = C5_GROUP * N_SECTORS
-    outs = [(torch.empty((nv, PH, SW, 4), dtype=torch.uint8, device="cuda"),
-             torch.empty((nv, PH, SW), dtype=torch.float32, device="cuda")) for _ in range(in_flight)]
+    CHUNK = 64                           # viewpoints per topo_render_batch call (1 GiB of RGBA + 1 GiB of depth)
+    eyes = np.stack([v[0] for v in mine]).astype(np.float32)
+    yaws = np.array([v[1] for v in mine], np.float32)
+    suns = np.array([(v[2], v[3]) for v in mine], np.float32)
+    rgba = torch.empty((min(CHUNK, len(mine)), N_SECTORS, PH, SW, 4), dtype=torch.uint8, device="cuda")
+    depth = torch.empty((min(CHUNK, len(mine)), N_SECTORS, PH, SW), dtype=torch.float32, device="cuda")
 
     def step():      # one step = this rank's whole share of the batch
-        for i, vs in enumerate(sets):
-            strip, depth = outs[i % in_flight]
-            r.render_views_device(vs, SW, PH, strip.data_ptr(), PH * SW * 4, SW * 4, depth.data_ptr(), PH * SW * 4, SW * 4)
+        for c0 in range(0, len(mine), CHUNK):
+            r.render_batch(eyes[c0:c0 + CHUNK], yaws[c0:c0 + CHUNK], suns[c0:c0 + CHUNK], SW, PH, rgba.data_ptr(), depth.data_ptr(), args.view_mode)
 
     def fence():
         r.join()
@@ -396,7 +494,7 @@ def bench_batch(args, T, np, torch, dist, r, locs, deg, SW, PH, rank, world, set
            "n_gpus": world, "steps": steps, "warmup": min(args.warmup, 1), "ms_per_step": round(ms, 3), "higher_is_better": True,
            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"c5: batch of {C5_VIEWPOINTS} viewpoints over the {deg}x{deg} deg mosaic, {N_SECTORS * SW}x{PH} panorama each",
-                      "frames_in_flight": in_flight, "viewpoints_per_submission": C5_GROUP,
+                      "frames_in_flight": in_flight, "viewpoints_per_submission": C5_GROUP, "entry_point": "topo_render_batch",
                       "sharding": f"viewpoints, {per} per GPU, DEM replicated, no collective"},
            "ms_per_viewpoint": round(ms / per, 4), "setup_s": round(setup_s, 1)}
     if rank == 0:
@@ -420,7 +518,7 @@ def cpu_baseline(T, np, locs, vlat, vlon, views, SW, PH, threads):
     t0 = time.perf_counter()
     o.render_views(views, threads=cores)
     dt = time.perf_counter() - t0
-    return {"value": round(N_SECTORS * SW * PH / 1e6 / dt, 3), "unit": "Mpix/s", "cores": cores, "kind": "port",
+    return {"value": round(N_SECTORS * SW * PH / 1e6 / dt, 3), "unit": "Mpix/s", "cores": cores, "host_cores": os.cpu_count(), "kind": "port",
             "seconds": round(dt, 2),
             "sample": f"one full panorama: all 8 sectors at full size ({N_SECTORS * SW}x{PH}) over {len(sample)} of the {len(locs)} tiles; "
                       f"oracle/topo_oracle.cpp, one OpenMP thread per sector"}

@@ -112,6 +112,43 @@ int topo_render_views_device(topo_ctx* ctx, uint32_t n_views, const topo_uniform
                              uint32_t height, uint8_t* rgba_dev, size_t rgba_view_stride, size_t rgba_pitch,
                              float* depth_dev, size_t depth_view_stride, size_t depth_pitch);
 
+/* ---- multi-GPU: the 360-degree strip sharded by azimuth sector, and the viewpoint batch ---------------------------
+ * (no reference counterpart: the reference renders one perspective view on one GPU.)
+ * One process per GPU, each with its own topo_ctx over the same tiles (the DEM is replicated: 1.15 GB of 288 GB).  The
+ * strip is TOPO_PANORAMA_SECTORS = 8 fixed sectors of sector_w x sector_h (the cameras of topo_panorama_uniforms), stored
+ * SECTOR-MAJOR -- uint8 strip[8][sector_h][sector_w][4], float depth[8][sector_h][sector_w] -- so that the share of rank g,
+ * sectors [8g/N, 8(g+1)/N), is one contiguous block.  topo_render_panorama renders this rank's sectors in one submission
+ * into their place in strip_dev / depth_dev (device pointers, caller-owned, the same size on every rank) and then
+ * all-gathers in place over RCCL (xGMI) on the context's stream: after topo_synchronize every rank holds the whole
+ * strip, bit-identical for every N.  comm == NULL (or a world of 1): all 8 sectors, no collective.
+ * RCCL is bound at run time (dlopen of librccl.so); nothing else in this library needs it.
+ *
+ * Call sequence for N ranks: rank 0 calls topo_comm_unique_id and hands the 128 bytes to the other ranks through the
+ * host's own channel (a file, a socket, MPI, ...); every rank calls topo_comm_init(&comm, its_device, id, rank, N)
+ * (collective: returns when all N have joined), loads the same tiles, then calls topo_render_panorama with the same
+ * arguments; topo_comm_destroy at the end.  A host that already owns an ncclComm_t (e.g. one created by PyTorch) wraps it
+ * with topo_comm_from_nccl instead; it is borrowed, not destroyed. */
+#define TOPO_PANORAMA_SECTORS 8u
+#define TOPO_COMM_ID_BYTES 128u
+typedef struct topo_comm topo_comm;
+int topo_comm_unique_id(uint8_t out_id[TOPO_COMM_ID_BYTES]);
+int topo_comm_init(topo_comm** out, int hip_device, const uint8_t id[TOPO_COMM_ID_BYTES], int rank, int world);
+int topo_comm_from_nccl(topo_comm** out, void* nccl_comm, int rank, int world);
+void topo_comm_destroy(topo_comm* comm);
+/* The sectors rank `rank` of `world` renders: [*first, *first + *count). */
+void topo_panorama_sector_range(int rank, int world, uint32_t* first, uint32_t* count);
+int topo_render_panorama(topo_ctx* ctx, topo_comm* comm, const float eye[3], float yaw0, float pitch, uint32_t sector_w,
+                         uint32_t sector_h, float sun_theta_deg, float sun_phi_deg, int32_t view_mode, uint8_t* strip_dev,
+                         float* depth_dev /* nullable */);
+/* BASELINE config 5 (throughput mode): n_viewpoints independent panoramas -- viewpoint v has eye eyes_xyz[3v..], first
+ * sector yaw yaw0[v], sun (sun_theta_phi_deg[2v], [2v+1]) -- into rgba_dev[v][8][sector_h][sector_w][4] (and depth_dev
+ * likewise, nullable).  Eight viewpoints (64 views) go into one submission and, with topo_set_pipeline_depth(d), d
+ * submissions are in flight; asynchronous (topo_join / topo_synchronize).  Viewpoints are independent: a multi-GPU host
+ * gives each rank its own share of the batch, there is no collective. */
+int topo_render_batch(topo_ctx* ctx, uint32_t n_viewpoints, const float* eyes_xyz, const float* yaw0,
+                      const float* sun_theta_phi_deg, float pitch, uint32_t sector_w, uint32_t sector_h, int32_t view_mode,
+                      uint8_t* rgba_dev, float* depth_dev /* nullable */);
+
 /* RenderEngine::get_visible_labels(peaks, projection, size, depth_state, depth_buffer_view)   render_engine.rs:338-396
  * (the immediate consumer of the depth output, kept on the device so the pad_256 read-back
  * disappears).  For each peak (ECEF f32 xyz, PeakInstance.position): project_point3 through `camera_proj`; inside

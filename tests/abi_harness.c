@@ -21,13 +21,26 @@ int main(void) {
     if (topo_coordinate_transform(ps, 3, tp, 6, ps, rp, mp, sc) != TOPO_ERR_UNSUPPORTED) return 14;
     int32_t locs[64];
     if (topo_locations_range(45.5f, 15.5f, 100000.0f, locs, 32) == 0) return 15;
+    /* the multi-GPU entry points, degenerate world of one (needs neither RCCL nor a GPU) */
+    topo_comm* comm = NULL;
+    uint32_t first = 99, count = 99;
+    if (topo_comm_init(&comm, 0, NULL, 0, 1) != TOPO_OK || comm == NULL) return 17;
+    topo_panorama_sector_range(0, 1, &first, &count);
+    if (first != 0 || count != TOPO_PANORAMA_SECTORS) return 18;
+    topo_panorama_sector_range(3, 4, &first, &count);
+    if (first != 6 || count != 2) return 19;
+    topo_comm* bad = NULL;
+    if (topo_comm_init(&bad, 0, NULL, 0, 3) != TOPO_ERR_INVALID || bad != NULL) return 20;      /* 8 sectors do not divide by 3 */
+    if (topo_comm_init(&bad, 0, NULL, 2, 2) != TOPO_ERR_INVALID) return 21;
     topo_ctx* ctx = NULL;
     const int rc = topo_create(&ctx, 0, 64, 64, TOPO_FORMAT_RGBA8_UNORM_SRGB);
     if (rc == TOPO_OK) {                 /* a GPU is present: the context works and goes away again */
+        if (topo_render_panorama(ctx, comm, eye, 0.0f, 0.0f, 64, 64, 15.5f, 45.5f, 0, NULL, NULL) != TOPO_ERR_INVALID) return 22;
         topo_destroy(ctx);
     } else if (rc != TOPO_ERR_HIP || ctx != NULL) {
         return 16;                       /* without a device: a clean error, no CPU fallback */
     }
+    topo_comm_destroy(comm);
     printf("abi harness ok (topo_create rc %d)\n", rc);
     return 0;
 }

@@ -39,6 +39,13 @@ def _worker(rank, world, port, expect_path, out_q):
         expect = torch.from_numpy(np.load(expect_path))          # [8, H, SW, 4] in sector order
         ok = all(bool(torch.equal(T.panorama.sector(strip, k), expect[k])) for k in range(8))
         ok = ok and bool(torch.equal(T.panorama.to_row_major(strip), expect.permute(1, 0, 2, 3).reshape(sh, 8 * sw, 4)))
+        # the sector-major layout of the C ABI (topo_render_panorama) and of bench.py: one in-place all-gather per panorama
+        strip2 = torch.zeros((8, sh, sw, 4), dtype=torch.uint8)
+        for c, k in enumerate(mine):
+            strip2[k] = torch.from_numpy(rgba[c])
+        T.panorama.gather_sector_major(dist, strip2, rank, world)
+        ok = ok and bool(torch.equal(strip2, expect))
+        ok = ok and list(mine) == list(T.panorama_sector_range(rank, world))      # the C ABI's split is the same split
         out_q.put((rank, ok, list(mine)))
     finally:
         dist.destroy_process_group()

@@ -960,3 +960,52 @@ def test_occlusion_filter_is_conservative_on_coarse_tiles(topo, orc, tile, n, sp
         assert tested == 0          # sagitta 206 m / 53 m / 5.5 m: beyond the allowance, never filtered
     else:
         assert tested > 0           # 720-px tiles: 0.95 m -- filtered, with the sagitta added to the slab
+
+
+def test_panorama_and_batch_entry_points(topo, orc):
+    """topo_render_panorama (world of one: all 8 sectors, no collective) and topo_render_batch -- the multi-GPU entry points of
+    the C ABI -- produce what topo_render_views_device produces from the same cameras; one sector and one batch viewpoint
+    against the oracle."""
+    import torch
+    sc = Scene(96, 2, 2, eye_dh=120.0)
+    sw, sh = 96, 160
+    g, o = both(topo, orc, sw, sh)
+    sc.load(g)
+    sc.load(o)
+    g.set_stream(torch.cuda.current_stream().cuda_stream)
+    comm = topo.Comm(0, 1)
+    assert list(topo.panorama_sector_range(0, 1)) == list(range(8)) and list(topo.panorama_sector_range(1, 4)) == [2, 3]
+    strip = torch.zeros((8, sh, sw, 4), dtype=torch.uint8, device="cuda")
+    depth = torch.zeros((8, sh, sw), dtype=torch.float32, device="cuda")
+    yaw0 = math.radians(25.0)
+    for use_comm in (comm, None):
+        strip.zero_(); depth.zero_()
+        g.render_panorama(use_comm, sc.eye, yaw0, sw, sh, sc.vlon, sc.vlat, strip.data_ptr(), depth.data_ptr())
+        g.synchronize()
+        views = sc.panorama(sw, sh, yaw0_deg=25.0)
+        ra, da = _strip(topo, g, views, sw, sh)
+        assert np.array_equal(strip.cpu().numpy(), ra) and np.array_equal(depth.cpu().numpy().view(np.uint32), da.view(np.uint32))
+    o.update(sw, sh, views[3], topo.post_uniforms(sw, sh))
+    assert_same_frame((ra[3], da[3]), o.render(), "panorama sector 3")
+    # batch: 11 viewpoints (one full group of 8 + a partial one), two submissions in flight
+    rng = np.random.default_rng(9)
+    eyes, yaws, suns = [], [], []
+    for _ in range(11):
+        lat, lon = 45.1 + 1.8 * rng.random(), 15.1 + 1.8 * rng.random()
+        key = (int(math.floor(lat)), int(math.floor(lon)))
+        ground = topo.synth.height_at(sc.heights[key], key[0], key[1], lon, lat)
+        eyes.append(topo.geometry_transform(ground + 80.0, lon, lat)); yaws.append(2 * math.pi * rng.random()); suns.append((lon, lat))
+    out = torch.zeros((11, 8, sh, sw, 4), dtype=torch.uint8, device="cuda")
+    dout = torch.zeros((11, 8, sh, sw), dtype=torch.float32, device="cuda")
+    g.set_pipeline_depth(2)
+    g.render_batch(eyes, yaws, suns, sw, sh, out.data_ptr(), dout.data_ptr())
+    g.join()
+    g.set_pipeline_depth(1)
+    for v in (0, 7, 8, 10):
+        views = topo.panorama_uniforms(eyes[v], yaws[v], sw, sh, suns[v][0], suns[v][1], 0)
+        ra, da = _strip(topo, g, views, sw, sh)
+        assert np.array_equal(out[v].cpu().numpy(), ra) and np.array_equal(dout[v].cpu().numpy().view(np.uint32), da.view(np.uint32)), v
+    o.update(sw, sh, views[5], topo.post_uniforms(sw, sh))
+    assert_same_frame((out[10, 5].cpu().numpy(), dout[10, 5].cpu().numpy()), o.render(), "batch viewpoint 10 sector 5")
+    with pytest.raises(topo.TopoError):
+        topo.Comm(0, 3)                   # 8 sectors do not divide among 3 ranks

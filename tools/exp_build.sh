@@ -9,4 +9,4 @@ mkdir -p $R/exp
 { echo "name: $1"; echo "flags: $2"; echo "commit: $(git -C $R rev-parse HEAD)"; echo "date: $(date -u +%FT%TZ)"; echo "--- uncommitted diff of topo-renderer_amd/csrc ---"; git -C $R diff HEAD -- topo-renderer_amd/csrc; } > $R/exp/$1.recipe
 cd $R/topo-renderer_amd/csrc
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -Wno-unused-function -Wno-pass-failed $2 \
-  -shared -o $R/exp/libtopo_$1.so topo_kernels.hip -x hip terrain_renderer.cpp topo_capi.cpp geotiff.cpp -lz
+  -shared -o $R/exp/libtopo_$1.so topo_kernels.hip -x hip terrain_renderer.cpp topo_capi.cpp geotiff.cpp panorama.cpp -lz -ldl

@@ -100,6 +100,13 @@ def lib():
             "topo_set_pipeline_depth": (C.c_int, [vp, i32]),
             "topo_join": (C.c_int, [vp]),
             "topo_frame_status": (C.c_int, [vp, vp]),
+            "topo_comm_unique_id": (C.c_int, [vp]),
+            "topo_comm_init": (C.c_int, [C.POINTER(vp), C.c_int, vp, C.c_int, C.c_int]),
+            "topo_comm_from_nccl": (C.c_int, [C.POINTER(vp), vp, C.c_int, C.c_int]),
+            "topo_comm_destroy": (None, [vp]),
+            "topo_panorama_sector_range": (None, [C.c_int, C.c_int, vp, vp]),
+            "topo_render_panorama": (C.c_int, [vp, vp, vp, f32, f32, u32, u32, f32, f32, i32, vp, vp]),
+            "topo_render_batch": (C.c_int, [vp, u32, vp, vp, vp, f32, u32, u32, i32, vp, vp]),
             "topo_visible_peaks": (C.c_int, [vp, u32, vp, vp, vp]),
             "topo_visible_peaks_device": (C.c_int, [vp, vp, u32, u32, vp, sz, u32, vp, vp, vp]),
             "topo_camera_uniforms": (None, [vp, f32, f32, f32, f32, f32, f32, f32, i32, vp]),
@@ -251,6 +258,49 @@ def panorama_uniforms(eye, yaw0, sector_w, sector_h, sun_theta_deg, sun_phi_deg,
     return [out[k].copy() for k in range(n_sectors)]
 
 
+# ---- multi-GPU communicator (topo_comm_*: RCCL behind the C ABI) ---------------------------------------
+
+def comm_unique_id() -> np.ndarray:
+    """128 bytes from rank 0 (ncclGetUniqueId) for the host to hand to the other ranks."""
+    out = np.zeros(128, np.uint8)
+    rc = lib().topo_comm_unique_id(_p(out))
+    if rc != TOPO_OK:
+        raise TopoError(rc, lib().topo_last_error(None).decode())
+    return out
+
+
+class Comm:
+    """topo_comm: this process's place in a group of one-process-per-GPU renderers.  world == 1 needs no RCCL."""
+
+    def __init__(self, rank: int = 0, world: int = 1, unique_id=None, device: int = 0, nccl_comm: int = 0):
+        h = C.c_void_p()
+        if nccl_comm:
+            rc = lib().topo_comm_from_nccl(C.byref(h), C.c_void_p(nccl_comm), rank, world)
+        else:
+            uid = None if unique_id is None else np.ascontiguousarray(unique_id, dtype=np.uint8)
+            rc = lib().topo_comm_init(C.byref(h), device, None if uid is None else _p(uid), rank, world)
+        if rc != TOPO_OK:
+            raise TopoError(rc, lib().topo_last_error(None).decode())
+        self._h, self.rank, self.world = h, rank, world
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().topo_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def panorama_sector_range(rank: int, world: int):
+    a, b = C.c_uint32(), C.c_uint32()
+    lib().topo_panorama_sector_range(rank, world, C.byref(a), C.byref(b))
+    return range(a.value, a.value + b.value)
+
+
 # ---- the TerrainRenderer mirror ------------------------------------------------------------------------
 
 class TerrainRenderer:
@@ -337,6 +387,25 @@ class TerrainRenderer:
 
     def recompute_normals(self):
         self._check(lib().topo_recompute_normals(self._h))
+
+    def render_panorama(self, comm, eye, yaw0, sector_w, sector_h, sun_theta_deg, sun_phi_deg, strip_ptr: int, depth_ptr: int = 0,
+                        view_mode: int = 0, pitch: float = 0.0):
+        """topo_render_panorama: this rank's sectors into the sector-major strip [8][sector_h][sector_w][4] (+ depth), then the
+        in-place RCCL all-gather (comm None / world 1: all 8 sectors, no collective).  Asynchronous on the context's stream."""
+        e = np.ascontiguousarray(eye, dtype=np.float32)
+        self._check(lib().topo_render_panorama(self._h, comm._h if comm is not None else None, _p(e), yaw0, pitch, sector_w, sector_h,
+                                               sun_theta_deg, sun_phi_deg, view_mode, C.c_void_p(strip_ptr),
+                                               C.c_void_p(depth_ptr) if depth_ptr else None))
+
+    def render_batch(self, eyes, yaw0s, suns_theta_phi_deg, sector_w, sector_h, rgba_ptr: int, depth_ptr: int = 0, view_mode: int = 0,
+                     pitch: float = 0.0):
+        """topo_render_batch: n independent panoramas (eyes (n,3), yaw0s (n,), suns (n,2) degrees) into rgba [n][8][h][w][4]."""
+        e = np.ascontiguousarray(eyes, dtype=np.float32).reshape(-1, 3)
+        y = np.ascontiguousarray(yaw0s, dtype=np.float32).reshape(-1)
+        sn = np.ascontiguousarray(suns_theta_phi_deg, dtype=np.float32).reshape(-1, 2)
+        assert len(e) == len(y) == len(sn)
+        self._check(lib().topo_render_batch(self._h, len(e), _p(e), _p(y), _p(sn), pitch, sector_w, sector_h, view_mode,
+                                            C.c_void_p(rgba_ptr), C.c_void_p(depth_ptr) if depth_ptr else None))
 
     def render_views_device(self, uniforms_list, width, height, rgba_ptr: int, rgba_view_stride: int, rgba_pitch: int,
                             depth_ptr: int = 0, depth_view_stride: int = 0, depth_pitch: int = 0):

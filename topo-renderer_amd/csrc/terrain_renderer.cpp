@@ -950,6 +950,17 @@ void camera_uniforms(const float eye_in[3], float yaw, float pitch, float fov_y,
     out->view_mode = view_mode;
 }
 
+// The cameras of a 360-degree strip of n_sectors perspective sectors: sector k looks at yaw0 - k * 360/n
+// degrees with the vertical field of view that makes every sector 360/n degrees wide.
+void panorama_uniforms(const float eye[3], float yaw0, float pitch, uint32_t sector_w, uint32_t sector_h, float sun_theta_deg, float sun_phi_deg,
+                       int32_t view_mode, uint32_t n_sectors, topo_uniforms* out) {
+    const double kPi = 3.14159265358979323846;
+    const double fov = 2.0 * atan(tan(kPi / (double)n_sectors) * (double)sector_h / (double)sector_w);
+    for (uint32_t k = 0; k < n_sectors; ++k)
+        camera_uniforms(eye, (float)((double)yaw0 - (double)k * (2.0 * kPi / (double)n_sectors)), pitch, (float)fov, (float)sector_w,
+                        (float)sector_h, sun_theta_deg, sun_phi_deg, view_mode, out + k);
+}
+
 // UiController::get_locations_range (control/ui_controller.rs:61-83), f32 as in the reference.
 uint32_t locations_range(float latitude, float longitude, float range_dist, int32_t* out, uint32_t cap) {
     auto clampi = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };

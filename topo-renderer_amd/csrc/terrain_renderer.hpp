@@ -18,6 +18,9 @@
 
 namespace topo {
 
+constexpr uint32_t kPanoramaSectors = 8;      // fixed, independent of the GPU count, so the strip is the same for every N
+struct Comm;                                  // panorama.cpp: an RCCL communicator + this process's rank
+
 // BTreeMap<GeoLocation, _> key: Ord over {latitude{degree,direction S<N}, longitude{degree,direction W<E}}
 // (topo-common/src/lib.rs:7-38); GeoLocation::from_coord maps sign > 0 to N/E, else S/W (:102-121).
 using GeoKey = std::tuple<int, int, int, int>;
@@ -46,6 +49,10 @@ class TerrainRenderer {
     int render(uint8_t* rgba, size_t rgba_pitch, float* depth, size_t depth_pitch);
     int render_views_device(uint32_t n, const topo_uniforms* views, uint32_t w, uint32_t h, const OutputParams& out);
     int render_device(uint8_t* rgba_dev, size_t rgba_pitch, float* depth_dev, size_t depth_pitch);
+    int render_panorama(const Comm* comm, const float eye[3], float yaw0, float pitch, uint32_t sector_w, uint32_t sector_h, float sun_theta_deg,
+                        float sun_phi_deg, int32_t view_mode, uint8_t* strip_dev, float* depth_dev);
+    int render_batch(uint32_t n_viewpoints, const float* eyes, const float* yaw0s, const float* sun_theta_phi_deg, float pitch, uint32_t sector_w,
+                     uint32_t sector_h, int32_t view_mode, uint8_t* rgba_dev, float* depth_dev);
     int recompute_normals();
 
     int set_stream(hipStream_t s);
@@ -164,6 +171,13 @@ class TerrainRenderer {
 // host-side restatements of the reference's CPU math (glam 0.31)
 void camera_uniforms(const float eye[3], float yaw, float pitch, float fov_y, float width, float height,
                      float sun_theta_deg, float sun_phi_deg, int32_t view_mode, topo_uniforms* out);
+void panorama_uniforms(const float eye[3], float yaw0, float pitch, uint32_t sector_w, uint32_t sector_h, float sun_theta_deg, float sun_phi_deg,
+                       int32_t view_mode, uint32_t n_sectors, topo_uniforms* out);
+int comm_unique_id(uint8_t out[128], std::string* err);
+int comm_init(Comm** out, int device, const uint8_t id128[128], int rank, int world, std::string* err);
+int comm_from_nccl(Comm** out, void* nccl_comm, int rank, int world, std::string* err);
+void comm_destroy(Comm* c);
+void panorama_sector_range(int rank, int world, uint32_t* first, uint32_t* count);
 void geometry_transform(float h, float lon_deg, float lat_deg, float out[3]);
 void terrain_rotation(float model_lon_deg, float model_lat_deg, float rot3x3_colmajor[9]);
 uint32_t locations_range(float latitude, float longitude, float range_dist, int32_t* out_lat_lon, uint32_t cap);

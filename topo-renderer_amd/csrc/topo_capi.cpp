@@ -176,6 +176,72 @@ int topo_join(topo_ctx* ctx) {
     TOPO_CALL(ctx->r->join_frames());
 }
 
+// ---- multi-GPU panorama / viewpoint batch (panorama.cpp) -----------------------------------------------------
+struct topo_comm {
+    topo::Comm* c = nullptr;
+};
+
+int topo_comm_unique_id(uint8_t out_id[TOPO_COMM_ID_BYTES]) {
+    if (!out_id) return TOPO_ERR_INVALID;
+    try {
+        return topo::comm_unique_id(out_id, &g_create_error);
+    } catch (const std::exception& e) {
+        g_create_error = e.what();
+        return TOPO_ERR_HIP;
+    }
+}
+
+int topo_comm_init(topo_comm** out, int hip_device, const uint8_t id[TOPO_COMM_ID_BYTES], int rank, int world) {
+    if (!out || (world > 1 && !id)) return TOPO_ERR_INVALID;
+    *out = nullptr;
+    topo::Comm* c = nullptr;
+    static const uint8_t zero[TOPO_COMM_ID_BYTES] = {};
+    int rc;
+    try {
+        rc = topo::comm_init(&c, hip_device, id ? id : zero, rank, world, &g_create_error);
+    } catch (const std::exception& e) {
+        g_create_error = e.what();
+        return TOPO_ERR_HIP;
+    }
+    if (rc != TOPO_OK) return rc;
+    *out = new topo_comm();
+    (*out)->c = c;
+    return TOPO_OK;
+}
+
+int topo_comm_from_nccl(topo_comm** out, void* nccl_comm, int rank, int world) {
+    if (!out) return TOPO_ERR_INVALID;
+    *out = nullptr;
+    topo::Comm* c = nullptr;
+    if (int rc = topo::comm_from_nccl(&c, nccl_comm, rank, world, &g_create_error)) return rc;
+    *out = new topo_comm();
+    (*out)->c = c;
+    return TOPO_OK;
+}
+
+void topo_comm_destroy(topo_comm* comm) {
+    if (!comm) return;
+    topo::comm_destroy(comm->c);
+    delete comm;
+}
+
+void topo_panorama_sector_range(int rank, int world, uint32_t* first, uint32_t* count) {
+    if (first && count && world >= 1 && rank >= 0 && rank < world) topo::panorama_sector_range(rank, world, first, count);
+}
+
+int topo_render_panorama(topo_ctx* ctx, topo_comm* comm, const float eye[3], float yaw0, float pitch, uint32_t sector_w, uint32_t sector_h,
+                         float sun_theta_deg, float sun_phi_deg, int32_t view_mode, uint8_t* strip_dev, float* depth_dev) {
+    TOPO_GUARD(ctx);
+    TOPO_CALL(ctx->r->render_panorama(comm ? comm->c : nullptr, eye, yaw0, pitch, sector_w, sector_h, sun_theta_deg, sun_phi_deg, view_mode,
+                                      strip_dev, depth_dev));
+}
+
+int topo_render_batch(topo_ctx* ctx, uint32_t n_viewpoints, const float* eyes_xyz, const float* yaw0, const float* sun_theta_phi_deg,
+                      float pitch, uint32_t sector_w, uint32_t sector_h, int32_t view_mode, uint8_t* rgba_dev, float* depth_dev) {
+    TOPO_GUARD(ctx);
+    TOPO_CALL(ctx->r->render_batch(n_viewpoints, eyes_xyz, yaw0, sun_theta_phi_deg, pitch, sector_w, sector_h, view_mode, rgba_dev, depth_dev));
+}
+
 int topo_frame_status(topo_ctx* ctx, uint32_t out[4]) {
     TOPO_GUARD(ctx);
     if (!out) return TOPO_ERR_INVALID;
@@ -198,10 +264,7 @@ float topo_sector_fov_y(uint32_t sector_w, uint32_t sector_h, uint32_t n_sectors
 
 void topo_panorama_uniforms(const float eye[3], float yaw0, float pitch, uint32_t sector_w, uint32_t sector_h, float sun_theta_deg,
                             float sun_phi_deg, int32_t view_mode, uint32_t n_sectors, topo_uniforms* out) {
-    const double fov = 2.0 * atan(tan(3.14159265358979323846 / (double)n_sectors) * (double)sector_h / (double)sector_w);
-    for (uint32_t k = 0; k < n_sectors; ++k)
-        topo::camera_uniforms(eye, (float)((double)yaw0 - (double)k * (2.0 * 3.14159265358979323846 / (double)n_sectors)), pitch, (float)fov,
-                              (float)sector_w, (float)sector_h, sun_theta_deg, sun_phi_deg, view_mode, out + k);
+    topo::panorama_uniforms(eye, yaw0, pitch, sector_w, sector_h, sun_theta_deg, sun_phi_deg, view_mode, n_sectors, out);
 }
 
 int topo_render_device(topo_ctx* ctx, uint8_t* rgba_dev, size_t rgba_pitch, float* depth_dev, size_t depth_pitch) {

@@ -50,6 +50,16 @@ def gather_slot(dist, strip, c: int, rank: int, world: int, async_op: bool = Fal
     return dist.all_gather_into_tensor(out.view(-1), out[rank].reshape(-1), async_op=async_op)
 
 
+def gather_sector_major(dist, strip, rank: int, world: int, async_op: bool = False):
+    """The layout of the C ABI (topo_render_panorama): strip[8][H][SW][C] in sector order, rank g's sectors
+    [8g/N, 8(g+1)/N) one contiguous block, ONE in-place all-gather per panorama.  This rank's block must already be in
+    place.  Returns the work handle when async_op (None for world == 1)."""
+    if world == 1 or dist is None:
+        return None
+    per = strip.shape[0] // world
+    return dist.all_gather_into_tensor(strip.view(-1), strip[rank * per:(rank + 1) * per].reshape(-1), async_op=async_op)
+
+
 def to_row_major(strip):
     """[per, world, H, SW, C] -> [H, n_sectors*SW, C] (the strip as one image, sectors left to right)."""
     per, world, h, sw = strip.shape[0], strip.shape[1], strip.shape[2], strip.shape[3]
