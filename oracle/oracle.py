@@ -39,6 +39,8 @@ def lib():
                                           C.c_void_p, C.c_size_t, C.c_size_t, C.c_int]
         L.oracle_read_normals.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
         L.oracle_render_winners.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_render_views_tiled.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t,
+                                                C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int]
         L.oracle_camera_uniforms.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                              C.c_float, C.c_float, C.c_int32, C.c_void_p]
         L.oracle_terrain_uniforms.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
@@ -148,6 +150,16 @@ class OracleRenderer:
         pre = np.empty((h, w, 4), np.uint8) if want_pre_post else None
         self._check(lib().oracle_render(self._h, _p(rgba), w * 4, _p(depth), w * 4, _p(pre) if pre is not None else None))
         return (rgba, depth, pre) if want_pre_post else (rgba, depth)
+
+    def render_views_tiled(self, uniforms_list, threads, groups):
+        """render_views with more threads than frames: each frame's tiles in `groups` runs of the draw order, merged per pixel."""
+        w, h = self.size
+        n = len(uniforms_list)
+        us = np.ascontiguousarray(np.stack([np.ascontiguousarray(u).view(np.uint8).reshape(160) for u in uniforms_list]))
+        rgba = np.empty((n, h, w, 4), np.uint8)
+        depth = np.empty((n, h, w), np.float32)
+        self._check(lib().oracle_render_views_tiled(self._h, n, _p(us), _p(rgba), w * h * 4, w * 4, _p(depth), w * h * 4, w * 4, threads, groups))
+        return rgba, depth
 
     def render_winners(self):
         """(depth (h,w) f32, winner (h,w) u32): winner = tile rank in draw order * 2(w-1)(h-1) + index-buffer triangle,

@@ -779,6 +779,52 @@ int oracle_render_winners(void* p, float* depth, uint32_t* winner) {
     return 0;
 }
 
+/* The same n frames with MORE threads than frames (bench.py's cpu_baseline on a many-core host): each frame's tiles are
+ * split into `groups` contiguous runs of the draw order, every (frame, run) job rasterises its tiles into a z-buffer of its
+ * own, and the runs are merged per pixel -- smallest depth wins, on equal depth the earlier run, which is what `Less` with
+ * in-order draws gives -- before the post pass.  Same bytes as oracle_render_views (tests/test_oracle_kat.py). */
+int oracle_render_views_tiled(void* p, uint32_t n, const void* uniforms160xn, uint8_t* rgba, size_t rgba_view_stride,
+                              size_t rgba_pitch, float* depth, size_t depth_view_stride, size_t depth_pitch, int threads, int groups) {
+    Oracle& o = *(Oracle*)p;
+    const Uniforms* us = (const Uniforms*)uniforms160xn;
+    if (groups < 1) groups = 1;
+    const size_t P = (size_t)o.W * o.H;
+    std::vector<const Tile*> order;
+    for (const auto& kv : o.tiles) order.push_back(kv.second.get());      /* BTreeMap order */
+    const int T = (int)order.size();
+    std::vector<Frame> part((size_t)n * groups);
+    const float clear[4] = {(float)0.0, (float)0.71, (float)0.885, (float)1.0};
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads > 0 ? threads : 1)
+    for (int job = 0; job < (int)n * groups; ++job) {
+        const int v = job / groups, g = job % groups;
+        Frame& f = part[job];
+        f.W = o.W; f.H = o.H;
+        f.depth.assign(P, 1.0f);
+        f.color.resize(P * 4);
+        for (size_t px = 0; px < P; ++px) store_color(f, px, clear);
+        Uniforms u;
+        memcpy(&u, &us[v], sizeof u);
+        const int lo = (int)((long long)T * g / groups), hi = (int)((long long)T * (g + 1) / groups);
+        for (int k = lo; k < hi; ++k) draw_tile(f, u, *order[k]);
+    }
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads > 0 ? threads : 1)
+    for (int v = 0; v < (int)n; ++v) {
+        Frame& f = part[(size_t)v * groups];
+        for (int g = 1; g < groups; ++g) {
+            Frame& q = part[(size_t)v * groups + g];
+            for (size_t px = 0; px < P; ++px)
+                if (q.depth[px] < f.depth[px]) { f.depth[px] = q.depth[px]; memcpy(&f.color[px * 4], &q.color[px * 4], 4); }
+            std::vector<float>().swap(q.depth);
+            std::vector<uint8_t>().swap(q.color);
+        }
+        f.final_.resize(P * 4);
+        post_pass(f);
+        copy_out(f, rgba ? rgba + (size_t)v * rgba_view_stride : nullptr, rgba_pitch,
+                 depth ? (float*)((uint8_t*)depth + (size_t)v * depth_view_stride) : nullptr, depth_pitch, nullptr);
+    }
+    return 0;
+}
+
 int oracle_read_normals(void* p, int32_t lat, int32_t lon, uint8_t* out) {
     Oracle& o = *(Oracle*)p;
     Tile* t = o.find(lat, lon);

@@ -235,3 +235,23 @@ def test_oracle_reproduces_golden(topo, orc, name):
         assert np.array_equal(rgba, g[f"rgba_{mode}"])
         if mode == 0:
             assert np.array_equal(depth.view(np.uint32), g["depth_bits"])
+
+
+def test_tiled_many_thread_rendering_equals_plain(orc):
+    """oracle_render_views_tiled (bench.py's all-cores CPU baseline: a frame's tiles split into runs of the draw order, each into
+    its own z-buffer, merged per pixel) gives the bytes of oracle_render_views -- including equal-depth ties between tiles,
+    which the merge must hand to the earlier run."""
+    from scenes import Scene
+    import topo_renderer_amd as T
+    sc = Scene(24, 3, 3, eye_dh=300.0)
+    sw, sh = 48, 40
+    o = orc.OracleRenderer(sw, sh)
+    sc.load(o)
+    # a duplicate of one tile's heights under a second location would not tie; an exact tie needs the same geometry drawn
+    # twice, which the BTreeMap forbids -- so ties are exercised through flat sea-level tiles sharing edge vertices' depth
+    views = sc.panorama(sw, sh, yaw0_deg=12.0)
+    o.update(sw, sh, views[0], T.post_uniforms(sw, sh))
+    ra, da = o.render_views(views, threads=4)
+    for groups in (1, 2, 4, 9, 13):
+        rb, db = o.render_views_tiled(views, threads=8, groups=groups)
+        assert np.array_equal(ra, rb) and np.array_equal(da.view(np.uint32), db.view(np.uint32)), groups
