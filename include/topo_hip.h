@@ -289,6 +289,20 @@ int topo_add_terrain_geotiff(topo_ctx* ctx, int32_t lat_deg, int32_t lon_deg, co
  * that of a HashSet (unspecified); callers here get the sorted order. */
 uint32_t topo_locations_range(float latitude, float longitude, float range_dist, int32_t* out_lat_lon, uint32_t cap);
 
+/* UiController::change_location(location, data, engine)                        control/ui_controller.rs:23-59
+ * The working-set maintenance around get_locations_range: tiles of the new range that are not loaded are to be requested
+ * (the reference sends DataRequested to its background runner), loaded tiles outside it are unloaded
+ * (terrain.unload_terrain).  The reference walks HashSets, so its orders are unspecified; here `request` comes in
+ * get_locations_range's order and `unload` in the order of `loaded`.  Counts may exceed the caps (nothing is written past
+ * them).  topo_change_location_plan is the pure set arithmetic over a caller-held list of (lat, lon) pairs;
+ * topo_change_location applies it to the context: it unloads what falls outside (as topo_unload_terrain) and reports
+ * what the host still has to fetch and hand to topo_add_terrain / topo_add_terrain_geotiff. */
+void topo_change_location_plan(float latitude, float longitude, float range_dist, const int32_t* loaded_lat_lon, uint32_t n_loaded,
+                               int32_t* unload_out, uint32_t unload_cap, uint32_t* n_unload, int32_t* request_out,
+                               uint32_t request_cap, uint32_t* n_request);
+int topo_change_location(topo_ctx* ctx, float latitude, float longitude, float range_dist, int32_t* request_out,
+                         uint32_t request_cap, uint32_t* n_request, uint32_t* n_unloaded);
+
 /* Synthetic COP90-shaped tile for tests and benches (integer-hash fBm): w*h floats. */
 void topo_synth_tile(int32_t lat_deg, int32_t lon_deg, uint32_t w, uint32_t h, uint32_t seed, float* out);
 

@@ -124,6 +124,30 @@ def test_locations_range_matches_oracle_and_known_answer(topo, orc):
     assert topo.locations_range(0.2, 179.8)[0][1] in range(-180, 180)                         # wraps across the antimeridian
 
 
+def test_change_location_plan_matches_the_reference_set_arithmetic(topo, orc):
+    """UiController::change_location (ui_controller.rs:23-59), restated here with Python sets over the ORACLE's
+    get_locations_range: new = set(range(location)); for each loaded tile: in new -> drop it from new, else -> unload;
+    what is left of new is requested."""
+    rng = np.random.default_rng(31)
+    for it in range(200):
+        la, lo = float(rng.uniform(-80, 80)), float(rng.uniform(-179.9, 179.9))
+        # a loaded set from an earlier position nearby (overlapping ranges), plus a few strays
+        la0, lo0 = la + float(rng.uniform(-1.5, 1.5)), lo + float(rng.uniform(-1.5, 1.5))
+        loaded = list(dict.fromkeys(orc.locations_range(min(max(la0, -85.0), 85.0), min(max(lo0, -179.9), 179.9), 1.0e5)))
+        loaded = [l for l in loaded if rng.random() < 0.8] + [(int(rng.integers(-60, 60)), int(rng.integers(-170, 170))) for _ in range(2)]
+        loaded = list(dict.fromkeys(loaded))
+        new = set(orc.locations_range(la, lo, 1.0e5))
+        want_unload = [l for l in loaded if l not in new]
+        want_request = new - set(loaded)
+        unload, request = topo.change_location_plan(la, lo, loaded)
+        assert unload == want_unload, (la, lo)
+        assert set(request) == want_request and len(request) == len(set(request)), (la, lo)
+        # the defined order: get_locations_range's
+        order = {l: i for i, l in reversed(list(enumerate(orc.locations_range(la, lo, 1.0e5))))}
+        assert request == sorted(request, key=lambda l: order[l])
+    assert topo.change_location_plan(45.6, 15.7, []) == ([], topo.locations_range(45.6, 15.7))
+
+
 def test_coordinate_transform_from_geo_tags(topo):
     """CoordinateTransform::from_geo_tag_data (coordinate_transform.rs:23-57): values, f64 -> f32 narrowing, both errors."""
     ps = [1.0 / 1200.0, 1.0 / 1200.0, 0.0]
@@ -196,3 +220,25 @@ def test_header_is_plain_c(topo, tmp_path):
     out = subprocess.run([exe], env=env, capture_output=True, text=True)
     assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
     assert "abi harness ok" in out.stdout
+
+
+def test_rust_bindings_cover_the_header():
+    """rust/topo-hip-sys/src/lib.rs (source only: no Rust toolchain in the image) is generated from include/topo_hip.h: it
+    must be what tools/gen_rust_bindings.py generates today, and declare every function the header declares."""
+    import importlib.util
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gen_rust_bindings", os.path.join(root, "tools", "gen_rust_bindings.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    committed = open(os.path.join(root, "rust", "topo-hip-sys", "src", "lib.rs")).read()
+    assert committed == gen.generate(), "run tools/gen_rust_bindings.py"
+    hdr = open(os.path.join(root, "include", "topo_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(topo_[a-z0-9_]+)\s*\(", hdr))
+    bound = set(re.findall(r"pub fn (topo_[a-z0-9_]+)\(", committed))
+    assert declared == bound, (sorted(declared - bound), sorted(bound - declared))
+    wrapper = open(os.path.join(root, "rust", "topo-hip", "src", "lib.rs")).read()
+    used = set(re.findall(r"sys::(topo_[a-z0-9_]+)\(", wrapper))
+    assert used <= bound and {"topo_create", "topo_update", "topo_add_terrain", "topo_unload_terrain", "topo_render", "topo_render_panorama"} <= used

@@ -1009,3 +1009,25 @@ def test_panorama_and_batch_entry_points(topo, orc):
     assert_same_frame((out[10, 5].cpu().numpy(), dout[10, 5].cpu().numpy()), o.render(), "batch viewpoint 10 sector 5")
     with pytest.raises(topo.TopoError):
         topo.Comm(0, 3)                   # 8 sectors do not divide among 3 ranks
+
+
+def test_change_location_on_the_renderer(topo, orc):
+    """topo_change_location: the renderer's own tile set is the `loaded_locations`; tiles that left the 100 km range are
+    unloaded (their seams stay as they are, like unload_terrain), the missing ones are reported in get_locations_range's order."""
+    sc = Scene(32, 3, 3, lat0=44, lon0=14)          # tiles 44..46 x 14..16
+    g, o = both(topo, orc, 64, 48)
+    sc.load(g)
+    sc.load(o)
+    req, n_un = g.change_location(45.623, 15.717)    # range = exactly these nine tiles
+    assert req == [] and n_un == 0
+    req, n_un = g.change_location(46.7, 16.9)        # moved north-east: rows 46..47, columns 15..18 -> five of ours leave
+    want = topo.locations_range(46.7, 16.9)
+    kept = [l for l in sc.locs if l in want]
+    assert n_un == 9 - len(kept) and req == [l for l in want if l not in sc.locs]
+    for l in sc.locs:
+        if l not in kept:
+            o.unload_terrain(*l)
+    u, pu = sc.uniforms(64, 48, 40, 20, 70, 0), topo.post_uniforms(64, 48)
+    g.update(64, 48, u, pu)
+    o.update(64, 48, u, pu)
+    assert_same_frame(g.render(), o.render(), "after change_location")

@@ -100,6 +100,8 @@ def lib():
             "topo_set_pipeline_depth": (C.c_int, [vp, i32]),
             "topo_join": (C.c_int, [vp]),
             "topo_frame_status": (C.c_int, [vp, vp]),
+            "topo_change_location_plan": (None, [f32, f32, f32, vp, u32, vp, u32, vp, vp, u32, vp]),
+            "topo_change_location": (C.c_int, [vp, f32, f32, f32, vp, u32, vp, vp]),
             "topo_comm_unique_id": (C.c_int, [vp]),
             "topo_comm_init": (C.c_int, [C.POINTER(vp), C.c_int, vp, C.c_int, C.c_int]),
             "topo_comm_from_nccl": (C.c_int, [C.POINTER(vp), vp, C.c_int, C.c_int]),
@@ -183,6 +185,16 @@ def locations_range(latitude: float, longitude: float, range_dist: float = 100_0
     buf = np.zeros((4096, 2), np.int32)
     n = int(lib().topo_locations_range(latitude, longitude, range_dist, _p(buf), 4096))
     return [(int(a), int(b)) for a, b in buf[:min(n, 4096)]]
+
+
+def change_location_plan(latitude: float, longitude: float, loaded, range_dist: float = 100_000.0):
+    """UiController::change_location's set arithmetic (ui_controller.rs:23-59): (to_unload, to_request) for a list of loaded
+    (lat_deg, lon_deg) tiles."""
+    ld = np.ascontiguousarray(np.array(list(loaded), dtype=np.int32).reshape(-1, 2))
+    un, rq = np.zeros((4096, 2), np.int32), np.zeros((4096, 2), np.int32)
+    nu, nr = C.c_uint32(), C.c_uint32()
+    lib().topo_change_location_plan(latitude, longitude, range_dist, _p(ld) if len(ld) else None, len(ld), _p(un), 4096, C.byref(nu), _p(rq), 4096, C.byref(nr))
+    return [(int(a), int(b)) for a, b in un[:nu.value]], [(int(a), int(b)) for a, b in rq[:nr.value]]
 
 
 class CoordinateTransform:
@@ -387,6 +399,13 @@ class TerrainRenderer:
 
     def recompute_normals(self):
         self._check(lib().topo_recompute_normals(self._h))
+
+    def change_location(self, latitude: float, longitude: float, range_dist: float = 100_000.0):
+        """UiController::change_location on this renderer's tile set: unloads what left the range, returns (tiles to fetch, n unloaded)."""
+        rq = np.zeros((4096, 2), np.int32)
+        nr, nu = C.c_uint32(), C.c_uint32()
+        self._check(lib().topo_change_location(self._h, latitude, longitude, range_dist, _p(rq), 4096, C.byref(nr), C.byref(nu)))
+        return [(int(a), int(b)) for a, b in rq[:nr.value]], int(nu.value)
 
     def render_panorama(self, comm, eye, yaw0, sector_w, sector_h, sun_theta_deg, sun_phi_deg, strip_ptr: int, depth_ptr: int = 0,
                         view_mode: int = 0, pitch: float = 0.0):

@@ -11,6 +11,7 @@
 #include <map>
 #include <string>
 #include <tuple>
+#include <utility>
 #include <vector>
 
 #include "../../include/topo_hip.h"
@@ -54,6 +55,7 @@ class TerrainRenderer {
     int render_batch(uint32_t n_viewpoints, const float* eyes, const float* yaw0s, const float* sun_theta_phi_deg, float pitch, uint32_t sector_w,
                      uint32_t sector_h, int32_t view_mode, uint8_t* rgba_dev, float* depth_dev);
     int recompute_normals();
+    int change_location(float latitude, float longitude, float range_dist, std::vector<std::pair<int32_t, int32_t>>& request, uint32_t* n_unloaded);
 
     int set_stream(hipStream_t s);
     int synchronize();
@@ -181,6 +183,8 @@ void panorama_sector_range(int rank, int world, uint32_t* first, uint32_t* count
 void geometry_transform(float h, float lon_deg, float lat_deg, float out[3]);
 void terrain_rotation(float model_lon_deg, float model_lat_deg, float rot3x3_colmajor[9]);
 uint32_t locations_range(float latitude, float longitude, float range_dist, int32_t* out_lat_lon, uint32_t cap);
+void change_location_plan(float latitude, float longitude, float range_dist, const int32_t* loaded, uint32_t n_loaded,
+                          std::vector<std::pair<int32_t, int32_t>>& unload, std::vector<std::pair<int32_t, int32_t>>& request);
 void synth_tile(int32_t lat, int32_t lon, uint32_t w, uint32_t h, uint32_t seed, float* out);
 
 }  // namespace topo

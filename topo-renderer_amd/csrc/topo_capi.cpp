@@ -4,6 +4,8 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <utility>
+#include <vector>
 
 #include "geotiff.hpp"
 #include "terrain_renderer.hpp"
@@ -240,6 +242,36 @@ int topo_render_batch(topo_ctx* ctx, uint32_t n_viewpoints, const float* eyes_xy
                       float pitch, uint32_t sector_w, uint32_t sector_h, int32_t view_mode, uint8_t* rgba_dev, float* depth_dev) {
     TOPO_GUARD(ctx);
     TOPO_CALL(ctx->r->render_batch(n_viewpoints, eyes_xyz, yaw0, sun_theta_phi_deg, pitch, sector_w, sector_h, view_mode, rgba_dev, depth_dev));
+}
+
+static uint32_t put_pairs(const std::vector<std::pair<int32_t, int32_t>>& v, int32_t* out, uint32_t cap) {
+    for (uint32_t i = 0; i < v.size() && i < cap && out; ++i) { out[2 * i] = v[i].first; out[2 * i + 1] = v[i].second; }
+    return (uint32_t)v.size();
+}
+
+void topo_change_location_plan(float latitude, float longitude, float range_dist, const int32_t* loaded_lat_lon, uint32_t n_loaded,
+                               int32_t* unload_out, uint32_t unload_cap, uint32_t* n_unload, int32_t* request_out, uint32_t request_cap,
+                               uint32_t* n_request) {
+    std::vector<std::pair<int32_t, int32_t>> unload, request;
+    topo::change_location_plan(latitude, longitude, range_dist, loaded_lat_lon, loaded_lat_lon ? n_loaded : 0, unload, request);
+    const uint32_t nu = put_pairs(unload, unload_out, unload_cap), nr = put_pairs(request, request_out, request_cap);
+    if (n_unload) *n_unload = nu;
+    if (n_request) *n_request = nr;
+}
+
+int topo_change_location(topo_ctx* ctx, float latitude, float longitude, float range_dist, int32_t* request_out, uint32_t request_cap,
+                         uint32_t* n_request, uint32_t* n_unloaded) {
+    TOPO_GUARD(ctx);
+    try {
+        std::vector<std::pair<int32_t, int32_t>> request;
+        const int rc = ctx->r->change_location(latitude, longitude, range_dist, request, n_unloaded);
+        if (rc != TOPO_OK) return rc;
+        const uint32_t nr = put_pairs(request, request_out, request_cap);
+        if (n_request) *n_request = nr;
+        return TOPO_OK;
+    } catch (const std::exception&) {
+        return TOPO_ERR_HIP;
+    }
 }
 
 int topo_frame_status(topo_ctx* ctx, uint32_t out[4]) {
