@@ -34,9 +34,15 @@ typedef enum topo_status {
                                 * rare-triangle queue and is incomplete (see topo_join) */
 } topo_status;
 
-/* wgpu::TextureFormat::Rgba8UnormSrgb -- the only colour format of the headless path (render_engine.rs:77-84
- * prefers the sRGB variant of whatever the surface offers). */
+/* The surface format the reference picks: `surface_caps.formats[0]`, with the sRGB suffix when the surface also offers
+ * that variant (render_engine.rs:77-84); render target and final target share it (terrain_renderer.rs:88-93).  The *Srgb
+ * formats encode linear -> sRGB8 on store and decode on sample (so the pipeline encodes twice and decodes once in
+ * between); the plain formats store round(clamp(v) * 255) and sample c / 255.  Bgra differs from Rgba
+ * only in the byte order of the output texels (B G R A in memory). */
 #define TOPO_FORMAT_RGBA8_UNORM_SRGB 1u
+#define TOPO_FORMAT_BGRA8_UNORM_SRGB 2u
+#define TOPO_FORMAT_RGBA8_UNORM 3u
+#define TOPO_FORMAT_BGRA8_UNORM 4u
 
 /* `Uniforms`, #[repr(C)], 160 bytes: topo-renderer/src/render/data.rs:33-41 (WGSL mirror render_shader.wgsl:3-9).
  * Matrices are glam column-major. */

@@ -111,9 +111,13 @@ def pad_256(n: int) -> int:
 class OracleRenderer:
     """CPU restatement of TerrainRenderer (terrain_renderer.rs): new/update/add_terrain/unload_terrain/render."""
 
-    def __init__(self, width: int, height: int):
+    def __init__(self, width: int, height: int, color_format: int = 1):
         self._h = lib().oracle_create(width, height)
         self.size = (width, height)
+        if color_format != 1:
+            L = lib()
+            L.oracle_set_format.argtypes = [C.c_void_p, C.c_uint32]
+            self._check(L.oracle_set_format(self._h, color_format))
 
     def close(self):
         if self._h:

@@ -418,11 +418,19 @@ struct Frame {
      * (tile rank in draw order) * 2(w-1)(h-1) + index-buffer triangle; 0xFFFFFFFF = cleared */
     std::vector<uint32_t> winner;
     uint32_t cur_draw = 0;
+    /* the surface format RenderEngine::new picks (render_engine.rs:77-84: formats[0], with the sRGB suffix when the
+     * surface offers it) -- render target and final target share it (terrain_renderer.rs:88-93):
+     * 1 Rgba8UnormSrgb, 2 Bgra8UnormSrgb, 3 Rgba8Unorm, 4 Bgra8Unorm.  The Srgb formats encode on store and decode on
+     * sample; the plain ones store round(clamp(v) * 255) and sample c / 255.  Bgra only changes the byte order in memory. */
+    uint32_t format = 1;
 };
+inline bool format_is_srgb(uint32_t f) { return f == 1 || f == 2; }
+inline bool format_is_bgra(uint32_t f) { return f == 2 || f == 4; }
 
 void store_color(Frame& f, size_t p, const float c[4]) {
     uint8_t* o = &f.color[p * 4];
-    o[0] = srgb().encode(c[0]); o[1] = srgb().encode(c[1]); o[2] = srgb().encode(c[2]);
+    if (format_is_srgb(f.format)) { o[0] = srgb().encode(c[0]); o[1] = srgb().encode(c[1]); o[2] = srgb().encode(c[2]); }
+    else { o[0] = unorm8(c[0]); o[1] = unorm8(c[1]); o[2] = unorm8(c[2]); }
     o[3] = unorm8(c[3]);
 }
 
@@ -615,7 +623,9 @@ void post_pass(Frame& f) {
         for (int px = 0; px < W; ++px) {
             const size_t p = (size_t)py * W + px;
             const uint8_t* c8 = &f.color[p * 4];
-            float rc[4] = {srgb().decode[c8[0]], srgb().decode[c8[1]], srgb().decode[c8[2]], from_unorm8(c8[3])};
+            const bool is_srgb = format_is_srgb(f.format);
+            float rc[4] = {is_srgb ? srgb().decode[c8[0]] : from_unorm8(c8[0]), is_srgb ? srgb().decode[c8[1]] : from_unorm8(c8[1]),
+                           is_srgb ? srgb().decode[c8[2]] : from_unorm8(c8[2]), from_unorm8(c8[3])};
             float center_linear = dist_from_depth(f.depth[p]);
             float contour = 8.0f * center_linear;
             for (int i = -1; i <= 1; ++i)
@@ -627,15 +637,18 @@ void post_pass(Frame& f) {
             float a = smoothstep(0.05f, 0.15f, contour / center_linear);
             const float cc[4] = {0.0f, 0.0f, 0.0f, 1.0f};
             uint8_t* o = &f.final_[p * 4];
-            o[0] = srgb().encode(mix(rc[0], cc[0], a));
-            o[1] = srgb().encode(mix(rc[1], cc[1], a));
-            o[2] = srgb().encode(mix(rc[2], cc[2], a));
+            const float m0 = mix(rc[0], cc[0], a), m1 = mix(rc[1], cc[1], a), m2 = mix(rc[2], cc[2], a);
+            o[0] = is_srgb ? srgb().encode(m0) : unorm8(m0);
+            o[1] = is_srgb ? srgb().encode(m1) : unorm8(m1);
+            o[2] = is_srgb ? srgb().encode(m2) : unorm8(m2);
+            if (format_is_bgra(f.format)) std::swap(o[0], o[2]);      /* memory order of the surface texel: B G R A */
             o[3] = unorm8(mix(rc[3], cc[3], a));
         }
 }
 
 struct Oracle {
     uint32_t W = 0, H = 0;
+    uint32_t format = 1;
     std::map<GeoKey, std::unique_ptr<Tile>> tiles;
     Uniforms u{};
     PostUniforms pu{};
@@ -648,13 +661,14 @@ struct Oracle {
 };
 
 void render_frame(const Oracle& o, const Uniforms& u, Frame& f) {
-    f.W = o.W; f.H = o.H;
+    f.W = o.W; f.H = o.H; f.format = o.format;
     const size_t P = (size_t)o.W * o.H;
     f.depth.assign(P, 1.0f);
     f.color.resize(P * 4);
     f.final_.resize(P * 4);
     const float clear[4] = {(float)0.0, (float)0.71, (float)0.885, (float)1.0}; /* terrain_renderer.rs:379-384 */
-    for (size_t p = 0; p < P; ++p) store_color(f, p, clear);
+    store_color(f, 0, clear);      /* encode the clear colour once, then replicate the texel */
+    for (size_t p = 1; p < P; ++p) memcpy(&f.color[p * 4], &f.color[0], 4);
     uint32_t rank = 0;
     for (const auto& kv : o.tiles) {   /* BTreeMap order, :407-420 */
         draw_tile(f, u, *kv.second, rank * 2u * (kv.second->w - 1) * (kv.second->h - 1));
@@ -768,6 +782,14 @@ int oracle_render_views(void* p, uint32_t n, const void* uniforms160xn, uint8_t*
     return 0;
 }
 
+/* TerrainRenderer::new's `format` argument (terrain_renderer.rs:37; chosen at render_engine.rs:77-84): 1 Rgba8UnormSrgb,
+ * 2 Bgra8UnormSrgb, 3 Rgba8Unorm, 4 Bgra8Unorm */
+int oracle_set_format(void* p, uint32_t format) {
+    if (format < 1 || format > 4) return -1;
+    ((Oracle*)p)->format = format;
+    return 0;
+}
+
 /* As oracle_render, additionally reporting which draw owns each pixel (ray_check.py compares it with a ray cast). */
 int oracle_render_winners(void* p, float* depth, uint32_t* winner) {
     Oracle& o = *(Oracle*)p;
@@ -798,10 +820,11 @@ int oracle_render_views_tiled(void* p, uint32_t n, const void* uniforms160xn, ui
     for (int job = 0; job < (int)n * groups; ++job) {
         const int v = job / groups, g = job % groups;
         Frame& f = part[job];
-        f.W = o.W; f.H = o.H;
+        f.W = o.W; f.H = o.H; f.format = o.format;
         f.depth.assign(P, 1.0f);
         f.color.resize(P * 4);
-        for (size_t px = 0; px < P; ++px) store_color(f, px, clear);
+        store_color(f, 0, clear);
+        for (size_t px = 1; px < P; ++px) memcpy(&f.color[px * 4], &f.color[0], 4);
         Uniforms u;
         memcpy(&u, &us[v], sizeof u);
         const int lo = (int)((long long)T * g / groups), hi = (int)((long long)T * (g + 1) / groups);

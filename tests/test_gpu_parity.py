@@ -1031,3 +1031,21 @@ def test_change_location_on_the_renderer(topo, orc):
     g.update(64, 48, u, pu)
     o.update(64, 48, u, pu)
     assert_same_frame(g.render(), o.render(), "after change_location")
+
+
+@pytest.mark.parametrize("fmt", [1, 2, 3, 4], ids=["rgba_srgb", "bgra_srgb", "rgba_unorm", "bgra_unorm"])
+def test_surface_formats(topo, orc, fmt):
+    """The four surface formats the reference can end up with (render_engine.rs:77-84), each bit-exact against the oracle:
+    terrain, contour transitions (the decode -> mix -> encode path of the post pass) and sky blocks."""
+    sc = Scene(64, 2, 2, eye_dh=90.0)
+    W, H = 200, 136
+    g, o = topo.TerrainRenderer(W, H, color_format=fmt), orc.OracleRenderer(W, H, color_format=fmt)
+    sc.load(g)
+    sc.load(o)
+    for yaw, pitch, mode in ((30, 12, 0), (200, 40, 1), (110, -5, 2)):
+        u, pu = sc.uniforms(W, H, yaw, pitch, 75, mode), topo.post_uniforms(W, H)
+        g.update(W, H, u, pu)
+        o.update(W, H, u, pu)
+        assert_same_frame(g.render(), o.render(), f"format {fmt} yaw {yaw}")
+    with pytest.raises(topo.TopoError):
+        topo.TerrainRenderer(W, H, color_format=7)

@@ -255,3 +255,28 @@ def test_tiled_many_thread_rendering_equals_plain(orc):
     for groups in (1, 2, 4, 9, 13):
         rb, db = o.render_views_tiled(views, threads=8, groups=groups)
         assert np.array_equal(ra, rb) and np.array_equal(da.view(np.uint32), db.view(np.uint32)), groups
+
+
+def test_surface_formats_of_the_oracle(orc):
+    """render_engine.rs:77-84 picks formats[0] (+ sRGB suffix when offered): Rgba/Bgra x Srgb/plain.  Bgra = the same texels,
+    B and R swapped in memory; the plain formats store round(clamp(v) * 255) -- the cleared sky (0, 0.71, 0.885, 1) becomes
+    (0, 181, 226, 255) instead of the sRGB codes -- and sample c / 255."""
+    from scenes import Scene
+    import topo_renderer_amd as T
+    sc = Scene(32, 1, 1, eye_dh=200.0)
+    W, H = 64, 48
+    frames = {}
+    for fmt in (1, 2, 3, 4):
+        o = orc.OracleRenderer(W, H, color_format=fmt)
+        sc.load(o)
+        o.update(W, H, sc.uniforms(W, H, 30, 20, 70, 0), T.post_uniforms(W, H))
+        frames[fmt] = o.render()
+    for a, b in ((1, 2), (3, 4)):
+        assert np.array_equal(frames[a][0][..., [2, 1, 0, 3]], frames[b][0]) and np.array_equal(frames[a][1], frames[b][1])
+    assert np.array_equal(frames[1][1], frames[3][1])                       # depth does not depend on the colour format
+    sky = frames[3][1] == 1.0
+    interior = sky & np.roll(sky, 1, 0) & np.roll(sky, -1, 0) & np.roll(sky, 1, 1) & np.roll(sky, -1, 1)
+    assert interior.any() and (frames[3][0][interior] == [0, 181, 226, 255]).all()
+    srgb_sky = frames[1][0][interior][0]
+    assert tuple(srgb_sky) == (0, 219, 242, 255)                            # the exact sRGB codes of 0.71 and 0.885
+    assert (frames[1][0] != frames[3][0]).any()

@@ -27,7 +27,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "topo_hip.h")
 
 TOPO_OK = 0
 TOPO_ERR_INVALID, TOPO_ERR_UNSUPPORTED, TOPO_ERR_HIP, TOPO_ERR_NOT_FOUND, TOPO_ERR_CAPACITY = -1, -2, -3, -4, -5
-FORMAT_RGBA8_UNORM_SRGB = 1
+FORMAT_RGBA8_UNORM_SRGB, FORMAT_BGRA8_UNORM_SRGB, FORMAT_RGBA8_UNORM, FORMAT_BGRA8_UNORM = 1, 2, 3, 4
 TIMING_SLOTS = 8
 TIMING_NAMES = ("clear", "cull", "raster", "occlusion", "raster_big", "resolve", "total", "load")
 

@@ -37,7 +37,10 @@ int TerrainRenderer::bind_device() {
 int TerrainRenderer::create(TerrainRenderer** out, int device, uint32_t w, uint32_t h, uint32_t format, std::string* err) {
     *out = nullptr;
     if (w == 0 || h == 0) { *err = "target size must be non-zero"; return TOPO_ERR_INVALID; }
-    if (format != TOPO_FORMAT_RGBA8_UNORM_SRGB) { *err = "only Rgba8UnormSrgb targets are supported"; return TOPO_ERR_UNSUPPORTED; }
+    if (format < TOPO_FORMAT_RGBA8_UNORM_SRGB || format > TOPO_FORMAT_BGRA8_UNORM) {
+        *err = "colour format must be Rgba8UnormSrgb, Bgra8UnormSrgb, Rgba8Unorm or Bgra8Unorm";
+        return TOPO_ERR_UNSUPPORTED;
+    }
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count == 0) {
@@ -50,6 +53,7 @@ int TerrainRenderer::create(TerrainRenderer** out, int device, uint32_t w, uint3
     r->device_ = device;
     r->W_ = w;
     r->H_ = h;
+    r->format_ = format;
     e = hipSetDevice(device);
     if (e == hipSuccess) e = hipStreamCreate(&r->own_stream_);
     for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreate(&r->load_ev_[i]);
@@ -458,7 +462,10 @@ int TerrainRenderer::render_frame(FrameCtx& c, hipStream_t stream, uint32_t n, c
     {   // the cleared render target texel: Color{0, 0.71, 0.885, 1} (terrain_renderer.rs:379-384) stored as Rgba8UnormSrgb
         float thresh[256];
         for (int i = 0; i < 256; ++i) thresh[i] = bits_f(TOPO_SRGB_THRESH_BITS[i]);
-        p.sky_c8 = srgb_encode(thresh, 0.0f) | (srgb_encode(thresh, 0.71f) << 8) | (srgb_encode(thresh, 0.885f) << 16) |
+        p.linear_target = (format_ == TOPO_FORMAT_RGBA8_UNORM || format_ == TOPO_FORMAT_BGRA8_UNORM) ? 1u : 0u;
+        p.bgra = (format_ == TOPO_FORMAT_BGRA8_UNORM_SRGB || format_ == TOPO_FORMAT_BGRA8_UNORM) ? 1u : 0u;
+        p.sky_c8 = (p.linear_target ? to_unorm8(0.0f) | (to_unorm8(0.71f) << 8) | (to_unorm8(0.885f) << 16)
+                                    : srgb_encode(thresh, 0.0f) | (srgb_encode(thresh, 0.71f) << 8) | (srgb_encode(thresh, 0.885f) << 16)) |
                    (to_unorm8(1.0f) << 24);
     }
     last_blocks_tested_ = (uint32_t)work_cap;

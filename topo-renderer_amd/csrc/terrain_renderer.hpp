@@ -96,6 +96,7 @@ class TerrainRenderer {
 
     int device_ = 0;
     uint32_t W_ = 0, H_ = 0;
+    uint32_t format_ = TOPO_FORMAT_RGBA8_UNORM_SRGB;
     uint32_t tile_w_ = 0, tile_h_ = 0;
     topo_uniforms uniforms_{};
     topo_post_uniforms post_{};

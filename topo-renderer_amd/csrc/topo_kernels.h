@@ -61,7 +61,9 @@ struct FrameParams {
     uint32_t bx_count, by_count;
     uint32_t tris_per_tile;
     FastDiv div_tris, div_hm1;   // exact division by tris_per_tile / (tile_h - 1)
-    uint32_t sky_c8;           // the cleared render-target texel (sRGB8-encoded clear colour)
+    uint32_t sky_c8;           // the cleared render-target texel (clear colour encoded for the target format), R G B A from the low byte
+    uint32_t linear_target;    // 1: plain *Unorm targets (no sRGB encode/decode); 0: *UnormSrgb
+    uint32_t bgra;             // 1: output texels are B G R A in memory
     uint32_t rblocks_x, rblocks_view;             // k_resolve's 64 x 16 px blocks: per row of a view, per view
     FastDiv div_rblocks_x, div_rblocks_view;
 };

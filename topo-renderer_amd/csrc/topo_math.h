@@ -352,28 +352,34 @@ TOPO_HD void shade_fragment(int view_mode, f3 sun, float cam_x, float cam_y, flo
 // offset -1..1, j inner = y offset -1..1, centre skipped).
 // kLut selects srgb_encode_lut (with `lut`) over srgb_encode: same result, fewer probes.
 template <bool kLut>
-TOPO_HD uint32_t post_pixel_t(const float* thresh, const float* decode, uint32_t c8, float center, const float ln[8], const uint8_t* lut) {
+TOPO_HD uint32_t post_pixel_t(const float* thresh, const float* decode, uint32_t c8, float center, const float ln[8], const uint8_t* lut,
+                              bool srgb_target = true) {
     // center / ln[] are ALREADY linear_depth() of the depth taps (each is a pure function of its texel, so a
     // kernel may compute it once per texel and share it between the up to nine pixels that tap it).
+    // srgb_target: the targets are *Srgb formats (decode on sample, encode on store); otherwise plain unorm8 both ways.
     float contour = 8.0f * center;
 #pragma unroll
     for (int k = 0; k < 8; ++k) contour -= ln[k];
     float t = sat(div_const(div_f(contour, center) - 0.05f, 0.15f - 0.05f, 1.0f / (0.15f - 0.05f)));   // center in [50, 5e5]
     const float a = t * t * (3.0f - 2.0f * t);
     // mix(x, 0, 0) = x*1 + 0*0 = x and the decode->encode round trip of a code is the identity (checked when the
-    // tables are generated), alpha stays 255; mix(x, 0, 1) = x*0 + 0*1 = 0: both ends skip the table work.
+    // tables are generated; to_unorm8(from_unorm8(c)) = c for the plain formats), alpha stays 255; mix(x, 0, 1) = x*0 + 0*1 = 0:
+    // both ends skip the table work.
     if (a == 0.0f && (c8 >> 24) == 255u) return c8;
     if (a == 1.0f && (c8 >> 24) == 255u) return 0xFF000000u;
-    const float r = decode[c8 & 255u] * (1.0f - a) + 0.0f * a;
-    const float g = decode[(c8 >> 8) & 255u] * (1.0f - a) + 0.0f * a;
-    const float b = decode[(c8 >> 16) & 255u] * (1.0f - a) + 0.0f * a;
+    const float dr = srgb_target ? decode[c8 & 255u] : from_unorm8(c8 & 255u), dg = srgb_target ? decode[(c8 >> 8) & 255u] : from_unorm8((c8 >> 8) & 255u),
+                db = srgb_target ? decode[(c8 >> 16) & 255u] : from_unorm8((c8 >> 16) & 255u);
+    const float r = dr * (1.0f - a) + 0.0f * a;
+    const float g = dg * (1.0f - a) + 0.0f * a;
+    const float b = db * (1.0f - a) + 0.0f * a;
     const float al = from_unorm8(c8 >> 24) * (1.0f - a) + 1.0f * a;
+    if (!srgb_target) return to_unorm8(r) | (to_unorm8(g) << 8) | (to_unorm8(b) << 16) | (to_unorm8(al) << 24);
     if (kLut) return srgb_encode_lut3(thresh, lut, r, g, b) | (to_unorm8(al) << 24);
     return srgb_encode(thresh, r) | (srgb_encode(thresh, g) << 8) | (srgb_encode(thresh, b) << 16) |
            (to_unorm8(al) << 24);
 }
-TOPO_HD uint32_t post_pixel(const float* thresh, const float* decode, uint32_t c8, float center, const float ln[8]) {
-    return post_pixel_t<false>(thresh, decode, c8, center, ln, nullptr);
+TOPO_HD uint32_t post_pixel(const float* thresh, const float* decode, uint32_t c8, float center, const float ln[8], bool srgb_target = true) {
+    return post_pixel_t<false>(thresh, decode, c8, center, ln, nullptr, srgb_target);
 }
 
 }  // namespace topo
