@@ -168,6 +168,28 @@ int topo_visible_peaks_device(topo_ctx* ctx, const topo_uniforms* view, uint32_t
                               const float* depth_dev, size_t depth_pitch, uint32_t n_peaks, const float* peaks_xyz_dev,
                               uint8_t* visible_dev, uint32_t* xy_dev);
 
+/* ---- overlay pass -------------------------------------------------------------------------
+ * LineRenderer::render (line_renderer.rs:200-212, resources/shaders/line_shader.wgsl): the label leader lines and label
+ * backgrounds, tessellated on the CPU (lyon, on the host's side) into a triangle list of `GpuVertex` (line_renderer.rs:18-25),
+ * drawn INTO the post pass: opaque, counter-clockwise front faces, back faces culled, depth test Greater with write against
+ * the post pass's depth attachment, which the post quad has filled with 1/4096 -- so z_index 2 (strokes) lies under 3
+ * (fills) under 100 (the text renderer's layer, text_renderer.rs:291), an equal z keeps the earlier triangle, and z_index
+ * <= 1 is never visible.  vs_main: z = z_index / 4096, p = (position + normal * line_width) * (1, -1),
+ * clip = (2 p.x / width - 1, 2 p.y / height + 1, z, 1); positions are pixels, y down.  The image is the context's
+ * width x height in its colour format (what topo_render / topo_render_device produced).  The glyph rasterisation of the
+ * reference's text renderer (glyphon) is a third-party renderer and stays on the host's side. */
+typedef struct topo_overlay_vertex {
+    float position[2];
+    float normal[2];
+    float color[3];      /* linear RGB; alpha is 1 */
+    int32_t z_index;
+} topo_overlay_vertex;   /* 32 bytes, = GpuVertex */
+int topo_overlay_lines(topo_ctx* ctx, const topo_overlay_vertex* vertices, uint32_t n_vertices, const uint32_t* indices,
+                       uint32_t n_indices, float line_width /* Primitive.width: 0.5 in the reference */, uint8_t* rgba /* host, in/out */,
+                       size_t rgba_pitch);
+int topo_overlay_lines_device(topo_ctx* ctx, const topo_overlay_vertex* vertices, uint32_t n_vertices, const uint32_t* indices,
+                              uint32_t n_indices, float line_width, uint8_t* rgba_dev /* device, in/out */, size_t rgba_pitch);
+
 /* Run the context's work on an existing hipStream_t (e.g. PyTorch's current stream); NULL restores the
  * context's own stream. */
 int topo_set_stream(topo_ctx* ctx, void* hip_stream);

@@ -165,6 +165,15 @@ class OracleRenderer:
         self._check(lib().oracle_render_views_tiled(self._h, n, _p(us), _p(rgba), w * h * 4, w * 4, _p(depth), w * h * 4, w * 4, threads, groups))
         return rgba, depth
 
+    def overlay_lines(self, vertices, indices, rgba, line_width=0.5):
+        """LineRenderer::render over `rgba` (h, w, 4) in place: vertices = structured/(n, 8) 32-byte GpuVertex records, indices u32."""
+        v = np.ascontiguousarray(vertices)
+        ix = np.ascontiguousarray(indices, dtype=np.uint32)
+        L = lib()
+        L.oracle_overlay_lines.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_float, C.c_void_p, C.c_size_t]
+        self._check(L.oracle_overlay_lines(self._h, _p(v), v.nbytes // 32, _p(ix), ix.size, line_width, _p(rgba), rgba.strides[0]))
+        return rgba
+
     def render_winners(self):
         """(depth (h,w) f32, winner (h,w) u32): winner = tile rank in draw order * 2(w-1)(h-1) + index-buffer triangle,
         0xFFFFFFFF where nothing was drawn.  Bookkeeping for oracle/ray_check.py."""

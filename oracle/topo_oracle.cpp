@@ -848,6 +848,76 @@ int oracle_render_views_tiled(void* p, uint32_t n, const void* uniforms160xn, ui
     return 0;
 }
 
+/* ---- overlay pass: LineRenderer::render (line_renderer.rs:200-212) with line_shader.wgsl, drawn into the post pass.
+ * Pipeline state: TriangleList, CCW front, back faces culled, no blending (line_renderer.rs:262-276); depth test Greater
+ * with write (pipeline.rs:24-32) against the attachment the post quad filled with 1/4096 (postprocessing_shader.wgsl:62).
+ * A classic in-order z-buffer: the triangles one after the other, fragment by fragment. */
+struct LineVertex { float position[2], normal[2], color[3]; int32_t z_index; };      /* GpuVertex, line_renderer.rs:18-25 */
+
+int oracle_overlay_lines(void* p, const void* vertices, uint32_t n_vertices, const uint32_t* indices, uint32_t n_indices, float width,
+                         uint8_t* rgba, size_t pitch) {
+    Oracle& o = *(Oracle*)p;
+    const LineVertex* vs = (const LineVertex*)vertices;
+    const uint32_t W = o.W, H = o.H;
+    std::vector<float> zbuf((size_t)W * H, 1.0f / 4096.0f);
+    for (uint32_t t = 0; t + 2 < n_indices; t += 3) {
+        ScreenVert sv[3];
+        const LineVertex* lv[3];
+        bool ok = true;
+        for (int k = 0; k < 3 && ok; ++k) {
+            if (indices[t + k] >= n_vertices) { ok = false; break; }
+            lv[k] = &vs[indices[t + k]];
+            /* vs_main, line_shader.wgsl:27-41 */
+            VSOut v{};
+            const float z = (float)lv[k]->z_index / 4096.0f;
+            const float px = lv[k]->position[0] + lv[k]->normal[0] * width, py = -(lv[k]->position[1] + lv[k]->normal[1] * width);
+            v.clip[0] = 2.0f * px / (float)W - 1.0f;
+            v.clip[1] = 2.0f * py / (float)H + 1.0f;
+            v.clip[2] = z;
+            v.clip[3] = 1.0f;
+            ok = to_screen(v, W, H, &sv[k]);
+        }
+        if (!ok) continue;
+        const int64_t area2 = (sv[1].X - sv[0].X) * (sv[2].Y - sv[0].Y) - (sv[1].Y - sv[0].Y) * (sv[2].X - sv[0].X);
+        if (area2 >= 0) continue;      /* back-facing or degenerate */
+        const int64_t minX = std::min(sv[0].X, std::min(sv[1].X, sv[2].X)), maxX = std::max(sv[0].X, std::max(sv[1].X, sv[2].X));
+        const int64_t minY = std::min(sv[0].Y, std::min(sv[1].Y, sv[2].Y)), maxY = std::max(sv[0].Y, std::max(sv[1].Y, sv[2].Y));
+        const int64_t x0 = std::max<int64_t>(0, floor_div(minX - 128 + 255, 256)), x1 = std::min<int64_t>((int64_t)W - 1, floor_div(maxX - 128, 256));
+        const int64_t y0 = std::max<int64_t>(0, floor_div(minY - 128 + 255, 256)), y1 = std::min<int64_t>((int64_t)H - 1, floor_div(maxY - 128, 256));
+        const float iA = 1.0f / (float)(-area2);
+        for (int64_t py = y0; py <= y1; ++py)
+            for (int64_t px = x0; px <= x1; ++px) {
+                const int64_t cx = px * 256 + 128, cy = py * 256 + 128;
+                int64_t F[3];
+                bool in = true;
+                for (int e = 0; e < 3; ++e) {      /* edge e: v[e+1] -> v[e+2], the weight of v[e]; top-left rule */
+                    const ScreenVert &a = sv[(e + 1) % 3], &b = sv[(e + 2) % 3];
+                    const int64_t dx = b.X - a.X, dy = b.Y - a.Y;
+                    F[e] = dy * (cx - a.X) - dx * (cy - a.Y);
+                    const bool owns = dy > 0 || (dy == 0 && dx < 0);
+                    if (F[e] < 0 || (F[e] == 0 && !owns)) in = false;
+                }
+                if (!in) continue;
+                const float b0 = (float)F[0] * iA, b1 = (float)F[1] * iA, b2 = (float)F[2] * iA;
+                const float z = fmaf(b1, sv[1].z - sv[0].z, fmaf(b2, sv[2].z - sv[0].z, sv[0].z));
+                if (!(z >= 0.0f && z <= 1.0f)) continue;
+                const size_t pix = (size_t)py * W + (size_t)px;
+                if (!(z > zbuf[pix])) continue;      /* CompareFunction::Greater */
+                zbuf[pix] = z;
+                const float iq = 1.0f / ((b0 + b1) + b2);      /* w = 1 for every vertex */
+                float c[3];
+                for (int k = 0; k < 3; ++k) c[k] = fmaf(lv[2]->color[k], b2, fmaf(lv[1]->color[k], b1, lv[0]->color[k] * b0)) * iq;
+                uint8_t* out = rgba + (size_t)py * pitch + (size_t)px * 4;
+                const bool is_srgb = format_is_srgb(o.format);
+                uint8_t r8 = is_srgb ? srgb().encode(c[0]) : unorm8(c[0]), g8 = is_srgb ? srgb().encode(c[1]) : unorm8(c[1]),
+                        b8 = is_srgb ? srgb().encode(c[2]) : unorm8(c[2]);
+                if (format_is_bgra(o.format)) std::swap(r8, b8);
+                out[0] = r8; out[1] = g8; out[2] = b8; out[3] = unorm8(1.0f);
+            }
+    }
+    return 0;
+}
+
 int oracle_read_normals(void* p, int32_t lat, int32_t lon, uint8_t* out) {
     Oracle& o = *(Oracle*)p;
     Tile* t = o.find(lat, lon);

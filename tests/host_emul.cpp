@@ -302,6 +302,48 @@ void emul_reference_triangle(const int32_t* X, const int32_t* Y, const float* z,
     }
 }
 
+// the overlay pass through the product's header functions, sequentially: keys raised by max (as k_overlay_raster's atomic
+// does), then coloured (k_overlay_resolve); srgb != 0: *Srgb target
+void emul_overlay_lines(const void* vertices, uint32_t n_vertices, const uint32_t* idx, uint32_t n_indices, float width, int W, int H, int srgb,
+                        int bgra, uint8_t* rgba, size_t pitch) {
+    const OverlayVertex* vs = (const OverlayVertex*)vertices;
+    std::vector<uint64_t> keys((size_t)W * H, kOverlayClear);
+    for (uint32_t t = 0; 3 * t + 2 < n_indices; ++t) {
+        const uint32_t i0 = idx[3 * t], i1 = idx[3 * t + 1], i2 = idx[3 * t + 2];
+        if (i0 >= n_vertices || i1 >= n_vertices || i2 >= n_vertices) continue;
+        SVert s0, s1, s2;
+        if (overlay_vertex(vs[i0], width, (float)W, (float)H, s0) != kVtxOk || overlay_vertex(vs[i1], width, (float)W, (float)H, s1) != kVtxOk ||
+            overlay_vertex(vs[i2], width, (float)W, (float)H, s2) != kVtxOk)
+            continue;
+        TriSetup ts;
+        if (!triangle_setup(s0, s1, s2, W, H, ts)) continue;
+        for (int py = ts.py0; py <= ts.py1; ++py) for (int px = ts.px0; px <= ts.px1; ++px) {
+            const int64_t cx = (int64_t)px * 256 + 128, cy = (int64_t)py * 256 + 128;
+            int64_t F[3]; bool in = true;
+            for (int e = 0; e < 3; ++e) { F[e] = ts.dy[e] * (cx - ts.ax[e]) - ts.dx[e] * (cy - ts.ay[e]); in = in && F[e] + ts.bias[e] >= 0; }
+            if (!in) continue;
+            const float z = fmaf((float)F[1] * ts.iA, ts.dz1, fmaf((float)F[2] * ts.iA, ts.dz2, ts.z0));
+            if (!(z >= 0.0f && z <= 1.0f)) continue;
+            const uint64_t key = overlay_key(z, t);
+            if (key > keys[(size_t)py * W + px]) keys[(size_t)py * W + px] = key;
+        }
+    }
+    float thresh[256];
+    for (int i = 0; i < 256; ++i) thresh[i] = bits_f(TOPO_SRGB_THRESH_BITS[i]);
+    for (int py = 0; py < H; ++py) for (int px = 0; px < W; ++px) {
+        const uint64_t key = keys[(size_t)py * W + px];
+        if (key <= kOverlayClear) continue;
+        const uint32_t t = 0xFFFFFFFFu - (uint32_t)key;
+        float rgb[3];
+        if (!overlay_color(vs[idx[3 * t]], vs[idx[3 * t + 1]], vs[idx[3 * t + 2]], width, W, H, px, py, rgb)) continue;
+        uint32_t out = srgb ? srgb_encode(thresh, rgb[0]) | (srgb_encode(thresh, rgb[1]) << 8) | (srgb_encode(thresh, rgb[2]) << 16)
+                            : to_unorm8(rgb[0]) | (to_unorm8(rgb[1]) << 8) | (to_unorm8(rgb[2]) << 16);
+        out |= to_unorm8(1.0f) << 24;
+        if (bgra) out = (out & 0xFF00FF00u) | ((out >> 16) & 0xFFu) | ((out & 0xFFu) << 16);
+        memcpy(rgba + (size_t)py * pitch + (size_t)px * 4, &out, 4);
+    }
+}
+
 float emul_from_unorm8(uint32_t c) { return from_unorm8(c); }
 
 uint64_t emul_vis_key(float z, uint32_t id) { return vis_key(z, id); }

@@ -70,3 +70,45 @@ def random_peaks(sc: "Scene", n=400, seed=5):
         ground = T.synth.height_at(sc.heights[(tl, to)], tl, to, lo, la)
         out[i] = T.geometry_transform(ground + rng.choice([-400.0, -30.0, 0.0, 5.0, 60.0, 800.0]), lo, la)
     return out
+
+
+OVERLAY_VERTEX = np.dtype([("position", np.float32, 2), ("normal", np.float32, 2), ("color", np.float32, 3), ("z_index", np.int32)])
+
+
+def overlay_geometry(W, H, n_lines=40, n_boxes=12, seed=3):
+    """Overlay triangles shaped like what the reference's LineRenderer tessellates (line_renderer.rs): leader lines as quads of
+    stroke vertices (position on the path + unit normal, widened by line_width in the shader, z_index 2) and label boxes as
+    filled rectangles (normal 0, z_index 3), plus a few triangles on the text layer (100), some clockwise (culled), some
+    partly off the target, some at z_index 0/1 (never visible) and some overlapping on the same layer (first one wins)."""
+    rng = np.random.default_rng(seed)
+    verts, idx = [], []
+
+    def quad(p, nrm, color, z):
+        base = len(verts)
+        for q, n in zip(p, nrm):
+            verts.append((tuple(q), tuple(n), tuple(color), z))
+        return base
+
+    for i in range(n_lines):
+        a, b = rng.uniform(-0.1, 1.1, 2) * [W, H], rng.uniform(-0.1, 1.1, 2) * [W, H]
+        d = (b - a) / max(1e-6, np.linalg.norm(b - a))
+        n = np.array([-d[1], d[0]], np.float32)
+        base = quad([a, a, b, b], [n, -n, n, -n], rng.uniform(0, 1, 3), 2 if i % 9 else int(rng.choice([0, 1, 5])))
+        tri = [base, base + 1, base + 2, base + 2, base + 1, base + 3]
+        if i % 7 == 3:
+            tri = tri[::-1]
+        idx += tri
+    for i in range(n_boxes):
+        x0, y0 = rng.uniform(0, 0.8, 2) * [W, H]
+        w, h = rng.uniform(5, 0.3 * W), rng.uniform(4, 20)
+        base = quad([(x0, y0), (x0 + w, y0), (x0 + w, y0 + h), (x0, y0 + h)], [(0, 0)] * 4, rng.uniform(0, 1, 3), 3)
+        idx += [base, base + 3, base + 2, base, base + 2, base + 1] if i % 2 else [base, base + 2, base + 1, base, base + 3, base + 2]
+    for i in range(6):
+        p = rng.uniform(0, 1, (3, 2)) * [W, H]
+        base = len(verts)
+        cols = rng.uniform(0, 1.2, (3, 3))              # per-vertex colours (interpolated), some above 1 (clamped by the store)
+        for q, c in zip(p, cols):
+            verts.append((tuple(q), (0.0, 0.0), tuple(c), 100))
+        idx += [base, base + 1, base + 2, base, base + 2, base + 1]      # both windings: one of them is front-facing
+    v = np.array(verts, dtype=OVERLAY_VERTEX)
+    return v, np.array(idx, np.uint32)

@@ -369,3 +369,21 @@ def test_normal_texel_fast_path():
         if rep == 1:
             assert nf.value < 0.8 * n           # on the boundaries the guard hands over
     assert total_fast > 10_000_000
+
+
+@pytest.mark.parametrize("fmt", [1, 4])
+def test_overlay_pass_header_code_matches_oracle(orc, fmt):
+    """The overlay pass (line_shader.wgsl over the post pass) through the product's header functions --
+    keys raised by max, then coloured -- against the oracle's in-order z-buffer with Greater."""
+    import ctypes as C
+    from scenes import overlay_geometry
+    L = emul.lib()
+    L.emul_overlay_lines.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+    for W, H, seed, width in ((160, 96, 1, 0.5), (97, 61, 2, 1.5), (64, 64, 3, 0.0)):
+        v, ix = overlay_geometry(W, H, seed=seed)
+        base = np.random.default_rng(seed).integers(0, 255, (H, W, 4), dtype=np.uint8)
+        a, b = base.copy(), base.copy()
+        orc.OracleRenderer(W, H, color_format=fmt).overlay_lines(v, ix, a, width)
+        L.emul_overlay_lines(emul._p(v), len(v), emul._p(ix), ix.size, width, W, H, 1 if fmt in (1, 2) else 0, 1 if fmt in (2, 4) else 0, emul._p(b), W * 4)
+        assert np.array_equal(a, b), f"{np.argwhere((a != b).any(axis=-1))[:5]}"
+        assert (a != base).any(axis=-1).mean() > 0.05

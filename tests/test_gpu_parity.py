@@ -1049,3 +1049,42 @@ def test_surface_formats(topo, orc, fmt):
         assert_same_frame(g.render(), o.render(), f"format {fmt} yaw {yaw}")
     with pytest.raises(topo.TopoError):
         topo.TerrainRenderer(W, H, color_format=7)
+
+
+@pytest.mark.parametrize("fmt", [1, 2, 3])
+def test_overlay_lines_over_a_rendered_frame(topo, orc, fmt):
+    """the line overlay (leader lines, label boxes; line_renderer.rs + line_shader.wgsl) drawn into the post
+    pass's image with the reference's layering -- host entry over the frame topo_render returned, device entry over the
+    frame topo_render_device left in HBM -- bit-exact against the oracle; a second overlay on the same renderer starts from
+    a clean layer buffer."""
+    import torch
+    from scenes import overlay_geometry
+    sc = Scene(64, 2, 2, eye_dh=120.0)
+    W, H = 200, 136
+    g, o = topo.TerrainRenderer(W, H, color_format=fmt), orc.OracleRenderer(W, H, color_format=fmt)
+    sc.load(g)
+    sc.load(o)
+    u, pu = sc.uniforms(W, H, 30, 12, 75, 0), topo.post_uniforms(W, H)
+    g.update(W, H, u, pu)
+    o.update(W, H, u, pu)
+    (rg, dg), (ro, do) = g.render(), o.render()
+    assert_same_frame((rg, dg), (ro, do), "base frame")
+    for seed, width in ((5, 0.5), (6, 2.0)):
+        v, ix = overlay_geometry(W, H, seed=seed)
+        a, b = np.ascontiguousarray(rg.copy()), np.ascontiguousarray(ro.copy())
+        g.overlay_lines(v, ix, a, width)
+        o.overlay_lines(v, ix, b, width)
+        assert np.array_equal(a, b), f"format {fmt} seed {seed}: {np.argwhere((a != b).any(axis=-1))[:5]}"
+        assert (a != rg).any(axis=-1).mean() > 0.05
+    # device entry: render + overlay without leaving HBM
+    img = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
+    g.set_stream(torch.cuda.current_stream().cuda_stream)
+    g.render_device(img.data_ptr(), W * 4)
+    g.overlay_lines_device(v, ix, img.data_ptr(), W * 4, width)
+    torch.cuda.synchronize()
+    assert np.array_equal(img.cpu().numpy(), b)
+    g.overlay_lines_device(v[:0], ix[:0], img.data_ptr(), W * 4, width)      # an empty overlay changes nothing
+    torch.cuda.synchronize()
+    assert np.array_equal(img.cpu().numpy(), b)
+    with pytest.raises(topo.TopoError):
+        g.overlay_lines(v, ix[:4], a, width)

@@ -280,3 +280,41 @@ def test_surface_formats_of_the_oracle(orc):
     srgb_sky = frames[1][0][interior][0]
     assert tuple(srgb_sky) == (0, 219, 242, 255)                            # the exact sRGB codes of 0.71 and 0.885
     assert (frames[1][0] != frames[3][0]).any()
+
+
+def test_overlay_layering_known_answers(orc):
+    """LineRenderer's pass (line_shader.wgsl, depth Greater against the post quad's 1/4096): a counter-clockwise (in y-down
+    pixel space: as lyon emits them... front = CCW after the shader's y flip) rectangle on layer 3 covers exactly its pixel
+    centres; layer 2 stays under it, layer 100 goes over it, layers 0 and 1 never show; an equal layer keeps the first."""
+    from scenes import OVERLAY_VERTEX
+    W, H = 32, 16
+    o = orc.OracleRenderer(W, H)
+
+    def rect(x0, y0, x1, y1, color, z, flip=False):
+        v = np.array([((x0, y0), (0, 0), color, z), ((x1, y0), (0, 0), color, z), ((x1, y1), (0, 0), color, z), ((x0, y1), (0, 0), color, z)], dtype=OVERLAY_VERTEX)
+        ix = [0, 3, 2, 0, 2, 1] if not flip else [0, 1, 2, 0, 2, 3]
+        return v, np.array(ix, np.uint32)
+
+    def draw(parts):
+        vs, ixs, base = [], [], 0
+        for v, ix in parts:
+            vs.append(v); ixs.append(ix + base); base += len(v)
+        img = np.zeros((H, W, 4), np.uint8)
+        return o.overlay_lines(np.concatenate(vs), np.concatenate(ixs), img)
+
+    red, green, blue = (1.0, 0.0, 0.0), (0.0, 1.0, 0.0), (0.0, 0.0, 1.0)
+    a = draw([rect(4, 2, 12, 10, red, 3)])
+    cov = (a[..., 3] == 255)
+    front = cov.sum() > 0
+    if not front:                                     # the other winding is the front-facing one
+        a = draw([rect(4, 2, 12, 10, red, 3, flip=True)])
+        cov = (a[..., 3] == 255)
+    flip = not front
+    assert cov.sum() == 8 * 8 and cov[2:10, 4:12].all() and (a[cov][:, :3] == [255, 0, 0]).all()
+    assert draw([rect(4, 2, 12, 10, red, 3, flip=not flip)])[..., 3].sum() == 0          # back face: culled
+    for z in (0, 1):
+        assert draw([rect(4, 2, 12, 10, red, z, flip=flip)])[..., 3].sum() == 0           # not Greater than 1/4096
+    over = draw([rect(4, 2, 12, 10, red, 3, flip=flip), rect(8, 4, 16, 12, green, 2, flip=flip), rect(0, 0, 6, 6, blue, 100, flip=flip)])
+    assert (over[5, 9, :3] == [255, 0, 0]).all() and (over[11, 9, :3] == [0, 255, 0]).all() and (over[3, 5, :3] == [0, 0, 255]).all()
+    same = draw([rect(4, 2, 12, 10, red, 3, flip=flip), rect(4, 2, 12, 10, green, 3, flip=flip)])
+    assert (same[5, 9, :3] == [255, 0, 0]).all()                                           # equal depth: the first draw stays

@@ -100,6 +100,8 @@ def lib():
             "topo_set_pipeline_depth": (C.c_int, [vp, i32]),
             "topo_join": (C.c_int, [vp]),
             "topo_frame_status": (C.c_int, [vp, vp]),
+            "topo_overlay_lines": (C.c_int, [vp, vp, u32, vp, u32, f32, vp, sz]),
+            "topo_overlay_lines_device": (C.c_int, [vp, vp, u32, vp, u32, f32, vp, sz]),
             "topo_change_location_plan": (None, [f32, f32, f32, vp, u32, vp, u32, vp, vp, u32, vp]),
             "topo_change_location": (C.c_int, [vp, f32, f32, f32, vp, u32, vp, vp]),
             "topo_comm_unique_id": (C.c_int, [vp]),
@@ -399,6 +401,20 @@ class TerrainRenderer:
 
     def recompute_normals(self):
         self._check(lib().topo_recompute_normals(self._h))
+
+    # LineRenderer::render (line_renderer.rs:200-212): overlay triangles over an image of this renderer's size and format
+    def overlay_lines(self, vertices, indices, rgba: np.ndarray, line_width: float = 0.5) -> np.ndarray:
+        """vertices: (n, 8) 4-byte words / structured array of 32-byte GpuVertex records; indices u32; rgba (h, w, 4) u8, in place."""
+        v = np.ascontiguousarray(vertices)
+        ix = np.ascontiguousarray(indices, dtype=np.uint32)
+        assert rgba.dtype == np.uint8 and rgba.flags.c_contiguous
+        self._check(lib().topo_overlay_lines(self._h, _p(v), v.nbytes // 32, _p(ix), ix.size, line_width, _p(rgba), rgba.strides[0]))
+        return rgba
+
+    def overlay_lines_device(self, vertices, indices, rgba_ptr: int, rgba_pitch: int, line_width: float = 0.5):
+        v = np.ascontiguousarray(vertices)
+        ix = np.ascontiguousarray(indices, dtype=np.uint32)
+        self._check(lib().topo_overlay_lines_device(self._h, _p(v), v.nbytes // 32, _p(ix), ix.size, line_width, C.c_void_p(rgba_ptr), rgba_pitch))
 
     def change_location(self, latitude: float, longitude: float, range_dist: float = 100_000.0):
         """UiController::change_location on this renderer's tile set: unloads what left the range, returns (tiles to fetch, n unloaded)."""

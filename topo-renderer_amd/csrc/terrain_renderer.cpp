@@ -79,7 +79,7 @@ TerrainRenderer::~TerrainRenderer() {
         (void)hipFree(kv.second.d_normals);
         (void)hipFree(kv.second.d_minmax);
     }
-    void* bufs[] = {d_tiles_, d_views_, d_out_rgba_, d_out_depth_, d_edge_jobs_, d_corner_jobs_, d_peaks_, d_proj_};
+    void* bufs[] = {d_tiles_, d_views_, d_out_rgba_, d_out_depth_, d_edge_jobs_, d_corner_jobs_, d_peaks_, d_proj_, d_overlay_geo_, d_overlay_keys_};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
     for (auto& c : ctx_) {
@@ -574,6 +574,47 @@ int TerrainRenderer::render(uint8_t* rgba, size_t rgba_pitch, float* depth, size
     have_depth_ = depth != nullptr;
     depth_w_ = W_;
     depth_h_ = H_;
+    return TOPO_OK;
+}
+
+// LineRenderer::render (line_renderer.rs:200-212) over an image this context produced: the overlay triangles are drawn
+// on top of the post pass's output with the reference's layering (depth Greater against the post quad's 1/4096).
+int TerrainRenderer::overlay_lines_device(const void* vertices, uint32_t n_vertices, const uint32_t* indices, uint32_t n_indices, float line_width,
+                                          uint8_t* rgba_dev, size_t rgba_pitch) {
+    if ((n_vertices && !vertices) || (n_indices && !indices) || !rgba_dev) return fail(TOPO_ERR_INVALID, "null argument");
+    if (n_indices % 3 != 0) return fail(TOPO_ERR_INVALID, "the overlay is a triangle list: index count must be a multiple of 3");
+    if (rgba_pitch < (size_t)W_ * 4) return fail(TOPO_ERR_INVALID, "pitch smaller than a row");
+    if (int rc = bind_device()) return rc;
+    const size_t vb = (size_t)n_vertices * sizeof(OverlayVertex), ib = (size_t)n_indices * 4, keys_b = (size_t)W_ * H_ * 8;
+    if (int rc = ensure(&d_overlay_geo_, &cap_overlay_geo_, ((vb + 15) & ~(size_t)15) + ib + 16)) return rc;
+    const bool fresh = keys_b > cap_overlay_keys_ || overlay_w_ != W_ || overlay_h_ != H_;
+    if (int rc = ensure(&d_overlay_keys_, &cap_overlay_keys_, keys_b)) return rc;
+    overlay_w_ = W_; overlay_h_ = H_;
+    uint8_t* geo = (uint8_t*)d_overlay_geo_;
+    uint32_t* d_idx = (uint32_t*)(geo + ((vb + 15) & ~(size_t)15));
+    if (vb) TOPO_HIP_TRY(hipMemcpyAsync(geo, vertices, vb, hipMemcpyHostToDevice, stream_));
+    if (ib) TOPO_HIP_TRY(hipMemcpyAsync(d_idx, indices, ib, hipMemcpyHostToDevice, stream_));
+    const uint32_t linear = (format_ == TOPO_FORMAT_RGBA8_UNORM || format_ == TOPO_FORMAT_BGRA8_UNORM) ? 1u : 0u;
+    const uint32_t bgra = (format_ == TOPO_FORMAT_BGRA8_UNORM_SRGB || format_ == TOPO_FORMAT_BGRA8_UNORM) ? 1u : 0u;
+    launch_overlay((const OverlayVertex*)geo, d_idx, n_indices / 3, n_vertices, line_width, (int32_t)W_, (int32_t)H_, (uint64_t*)d_overlay_keys_, fresh,
+                   rgba_dev, rgba_pitch, linear, bgra, stream_);
+    TOPO_HIP_TRY(hipStreamSynchronize(stream_));      // the geometry is only borrowed for the call
+    TOPO_HIP_TRY(hipGetLastError());
+    return TOPO_OK;
+}
+
+// Host image in, host image out (the frame topo_render returned, or any W x H image in the context's format).
+int TerrainRenderer::overlay_lines(const void* vertices, uint32_t n_vertices, const uint32_t* indices, uint32_t n_indices, float line_width,
+                                   uint8_t* rgba, size_t rgba_pitch) {
+    if (!rgba) return fail(TOPO_ERR_INVALID, "null argument");
+    if (rgba_pitch < (size_t)W_ * 4) return fail(TOPO_ERR_INVALID, "pitch smaller than a row");
+    if (int rc = bind_device()) return rc;
+    const size_t row = (size_t)W_ * 4;
+    if (int rc = ensure(&d_out_rgba_, &cap_out_rgba_, row * H_)) return rc;
+    TOPO_HIP_TRY(hipMemcpy2DAsync(d_out_rgba_, row, rgba, rgba_pitch, row, H_, hipMemcpyHostToDevice, stream_));
+    if (int rc = overlay_lines_device(vertices, n_vertices, indices, n_indices, line_width, (uint8_t*)d_out_rgba_, row)) return rc;
+    TOPO_HIP_TRY(hipMemcpy2DAsync(rgba, rgba_pitch, d_out_rgba_, row, row, H_, hipMemcpyDeviceToHost, stream_));
+    TOPO_HIP_TRY(hipStreamSynchronize(stream_));
     return TOPO_OK;
 }
 

@@ -55,6 +55,10 @@ class TerrainRenderer {
     int render_batch(uint32_t n_viewpoints, const float* eyes, const float* yaw0s, const float* sun_theta_phi_deg, float pitch, uint32_t sector_w,
                      uint32_t sector_h, int32_t view_mode, uint8_t* rgba_dev, float* depth_dev);
     int recompute_normals();
+    int overlay_lines_device(const void* vertices, uint32_t n_vertices, const uint32_t* indices, uint32_t n_indices, float line_width, uint8_t* rgba_dev,
+                             size_t rgba_pitch);
+    int overlay_lines(const void* vertices, uint32_t n_vertices, const uint32_t* indices, uint32_t n_indices, float line_width, uint8_t* rgba,
+                      size_t rgba_pitch);
     int change_location(float latitude, float longitude, float range_dist, std::vector<std::pair<int32_t, int32_t>>& request, uint32_t* n_unloaded);
 
     int set_stream(hipStream_t s);
@@ -164,6 +168,9 @@ class TerrainRenderer {
     int view_slot_ = 0;
     void* d_peaks_ = nullptr;    size_t cap_peaks_ = 0;      // xyz in, then visible + xy out
     void* d_proj_ = nullptr;     size_t cap_proj_ = 0;
+    void* d_overlay_geo_ = nullptr;  size_t cap_overlay_geo_ = 0;     // overlay vertices + indices
+    void* d_overlay_keys_ = nullptr; size_t cap_overlay_keys_ = 0;    // W*H overlay keys (depth | ~triangle), kept at the post quad's depth between calls
+    uint32_t overlay_w_ = 0, overlay_h_ = 0;
     bool have_depth_ = false;
     uint32_t depth_w_ = 0, depth_h_ = 0;
     uint32_t last_blocks_tested_ = 0;

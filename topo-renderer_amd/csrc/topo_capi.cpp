@@ -274,6 +274,18 @@ int topo_change_location(topo_ctx* ctx, float latitude, float longitude, float r
     }
 }
 
+int topo_overlay_lines(topo_ctx* ctx, const topo_overlay_vertex* vertices, uint32_t n_vertices, const uint32_t* indices, uint32_t n_indices,
+                       float line_width, uint8_t* rgba, size_t rgba_pitch) {
+    TOPO_GUARD(ctx);
+    TOPO_CALL(ctx->r->overlay_lines(vertices, n_vertices, indices, n_indices, line_width, rgba, rgba_pitch));
+}
+
+int topo_overlay_lines_device(topo_ctx* ctx, const topo_overlay_vertex* vertices, uint32_t n_vertices, const uint32_t* indices, uint32_t n_indices,
+                              float line_width, uint8_t* rgba_dev, size_t rgba_pitch) {
+    TOPO_GUARD(ctx);
+    TOPO_CALL(ctx->r->overlay_lines_device(vertices, n_vertices, indices, n_indices, line_width, rgba_dev, rgba_pitch));
+}
+
 int topo_frame_status(topo_ctx* ctx, uint32_t out[4]) {
     TOPO_GUARD(ctx);
     if (!out) return TOPO_ERR_INVALID;

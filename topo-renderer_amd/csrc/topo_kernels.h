@@ -109,6 +109,10 @@ void launch_raster_rare(const FrameParams& p, hipStream_t s);
 void launch_raster_big(const FrameParams& p, hipStream_t s);
 void launch_resolve(const FrameParams& p, const OutputParams& o, hipStream_t s);
 
+// overlay pass (line_shader.wgsl over the post pass's image): keys = W*H overlay keys, (re-)initialised when keys_fresh
+void launch_overlay(const OverlayVertex* verts, const uint32_t* idx, uint32_t n_tris, uint32_t n_verts, float width, int32_t W, int32_t H, uint64_t* keys,
+                    bool keys_fresh, uint8_t* rgba, size_t pitch, uint32_t linear_target, uint32_t bgra, hipStream_t s);
+
 // depth consumer (RenderEngine::get_visible_labels, render_engine.rs:338-396)
 void launch_visible_peaks(const float* proj16_dev, uint32_t w, uint32_t h, const float* depth, size_t depth_pitch, uint32_t n,
                           const float* peaks_xyz, uint8_t* visible, uint32_t* xy, hipStream_t s);

@@ -1248,6 +1248,76 @@ __global__ __launch_bounds__(256, TOPO_RESOLVE_WGS) void k_resolve(FrameParams P
 #undef TOPO_PROF
 }
 
+// ---- overlay pass (line_shader.wgsl) ------------------------------------------------------------------
+// Overlay geometry is a few hundred CPU-tessellated triangles: one lane per triangle walks its pixel box and raises the
+// pixel's overlay key (depth bits << 32 | ~triangle index) with a 64-bit atomic MAX -- `Greater` plus "the earlier draw
+// keeps an equal depth" -- over a key image that starts at the post quad's depth 1/4096; a second kernel colours the
+// pixels whose key moved.
+__global__ __launch_bounds__(64) void k_overlay_raster(const OverlayVertex* __restrict__ verts, const uint32_t* __restrict__ idx, uint32_t n_tris,
+                                                       uint32_t n_verts, float width, int32_t W, int32_t H, uint64_t* __restrict__ keys) {
+    const uint32_t t = blockIdx.x * 64 + threadIdx.x;
+    if (t >= n_tris) return;
+    const uint32_t i0 = idx[3 * t], i1 = idx[3 * t + 1], i2 = idx[3 * t + 2];
+    if (i0 >= n_verts || i1 >= n_verts || i2 >= n_verts) return;      // (wgpu rejects such a draw; here the triangle is skipped)
+    SVert s0, s1, s2;
+    if (overlay_vertex(verts[i0], width, (float)W, (float)H, s0) != kVtxOk || overlay_vertex(verts[i1], width, (float)W, (float)H, s1) != kVtxOk ||
+        overlay_vertex(verts[i2], width, (float)W, (float)H, s2) != kVtxOk)
+        return;
+    TriSetup ts;
+    if (!triangle_setup(s0, s1, s2, W, H, ts)) return;
+    for (int32_t py = ts.py0; py <= ts.py1; ++py)
+        for (int32_t px = ts.px0; px <= ts.px1; ++px) {
+            const int64_t cx = (int64_t)px * 256 + 128, cy = (int64_t)py * 256 + 128;
+            int64_t F[3];
+            bool in = true;
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+                F[e] = ts.dy[e] * (cx - ts.ax[e]) - ts.dx[e] * (cy - ts.ay[e]);
+                in = in && F[e] + ts.bias[e] >= 0;
+            }
+            if (!in) continue;
+            const float z = fmaf((float)F[1] * ts.iA, ts.dz1, fmaf((float)F[2] * ts.iA, ts.dz2, ts.z0));
+            if (!(z >= 0.0f && z <= 1.0f)) continue;      // clip volume 0 <= z <= w
+            atomicMax(reinterpret_cast<unsigned long long*>(keys + (size_t)py * W + px), (unsigned long long)overlay_key(z, t));
+        }
+}
+
+__global__ __launch_bounds__(256) void k_overlay_resolve(const OverlayVertex* __restrict__ verts, const uint32_t* __restrict__ idx, float width,
+                                                         int32_t W, int32_t H, uint64_t* __restrict__ keys, uint8_t* __restrict__ rgba, size_t pitch,
+                                                         uint32_t linear_target, uint32_t bgra) {
+    const int32_t px = blockIdx.x * 64 + (threadIdx.x & 63), py = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (px >= W || py >= H) return;
+    const uint64_t key = keys[(size_t)py * W + px];
+    keys[(size_t)py * W + px] = kOverlayClear;      // ready for the next frame's overlay
+    if (key <= kOverlayClear) return;                // nothing passed `Greater` here (an equal depth has a smaller low word)
+    const uint32_t t = 0xFFFFFFFFu - (uint32_t)key;
+    float rgb[3];
+    if (!overlay_color(verts[idx[3 * t]], verts[idx[3 * t + 1]], verts[idx[3 * t + 2]], width, W, H, px, py, rgb)) return;
+    uint32_t out;
+    if (linear_target) {
+        out = to_unorm8(rgb[0]) | (to_unorm8(rgb[1]) << 8) | (to_unorm8(rgb[2]) << 16);
+    } else {
+        float thresh[1];      // (the 8-probe search reads the table from constant memory: overlays are a few thousand pixels)
+        (void)thresh;
+        auto enc = [](float l) {
+            uint32_t lo = 0;
+#pragma unroll
+            for (uint32_t step = 128; step >= 1; step >>= 1)
+                if (bits_f(TOPO_SRGB_THRESH_BITS[lo + step - 1]) <= l) lo += step;
+            return lo;
+        };
+        out = enc(rgb[0]) | (enc(rgb[1]) << 8) | (enc(rgb[2]) << 16);
+    }
+    out |= to_unorm8(1.0f) << 24;
+    if (bgra) out = (out & 0xFF00FF00u) | ((out >> 16) & 0xFFu) | ((out & 0xFFu) << 16);
+    *reinterpret_cast<uint32_t*>(rgba + (size_t)py * pitch + (size_t)px * 4) = out;
+}
+
+__global__ __launch_bounds__(256) void k_overlay_init(uint64_t* __restrict__ keys, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) keys[i] = kOverlayClear;
+}
+
 // One lane per peak: project, one depth lookup, one comparison (render_engine.rs:338-396).
 __global__ __launch_bounds__(256) void k_visible_peaks(const float* __restrict__ proj, uint32_t w, uint32_t h,
                                                        const float* __restrict__ depth, size_t depth_pitch, uint32_t n,
@@ -1445,6 +1515,15 @@ void launch_resolve(const FrameParams& p, const OutputParams& o, hipStream_t s) 
     unsigned resident = 4u * resident_grid<3>(k_resolve, 256 * TOPO_RESOLVE_WGS);
     if (const char* e = getenv("TOPO_RESOLVE_GRID")) resident = (unsigned)atoi(e) ? (unsigned)atoi(e) : n_blocks;      // experiments: 0 = one block per workgroup
     hipLaunchKernelGGL(k_resolve, dim3(n_blocks < resident ? n_blocks : resident), dim3(256), 0, s, p, o);
+}
+
+void launch_overlay(const OverlayVertex* verts, const uint32_t* idx, uint32_t n_tris, uint32_t n_verts, float width, int32_t W, int32_t H, uint64_t* keys,
+                    bool keys_fresh, uint8_t* rgba, size_t pitch, uint32_t linear_target, uint32_t bgra, hipStream_t s) {
+    const size_t n = (size_t)W * H;
+    if (keys_fresh) hipLaunchKernelGGL(k_overlay_init, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, keys, n);
+    if (n_tris == 0) return;
+    hipLaunchKernelGGL(k_overlay_raster, dim3((n_tris + 63) / 64), dim3(64), 0, s, verts, idx, n_tris, n_verts, width, W, H, keys);
+    hipLaunchKernelGGL(k_overlay_resolve, dim3((W + 63) / 64, (H + 3) / 4), dim3(256), 0, s, verts, idx, width, W, H, keys, rgba, pitch, linear_target, bgra);
 }
 
 void launch_visible_peaks(const float* proj16_dev, uint32_t w, uint32_t h, const float* depth, size_t depth_pitch, uint32_t n,

@@ -712,6 +712,46 @@ TOPO_HD bool resolve_pixel(const TriRecord& rec, int32_t W, int32_t H, int32_t p
     return true;
 }
 
+// ---- overlay pass: line_shader.wgsl + LineRenderer's pipeline state ---------------------------------
+// The label leader lines and label backgrounds are CPU-tessellated (lyon) into `GpuVertex` triangles
+// (line_renderer.rs:18-25: position vec2, normal vec2, color vec3, z_index i32 = 32 bytes) and drawn INTO the post pass:
+// opaque (blend None), CCW front / back-face culled (:271-275), depth test Greater with write against the post pass's
+// depth attachment (pipeline.rs:24-32), which the full-screen post quad has just filled with z = 1/4096
+// (postprocessing_shader.wgsl:62).  vs_main (line_shader.wgsl:27-41): z = f32(z_index) / 4096;
+// p = (position + normal * width) * (1, -1); clip = (2 p.x / res_w - 1, 2 p.y / res_h + 1, z, 1).
+struct OverlayVertex {         // GpuVertex, #[repr(C)]
+    float position[2], normal[2], color[3];
+    int32_t z_index;
+};
+constexpr uint32_t kOverlayBaseDepthBits = 0x39800000u;      // 1.0f / 4096.0f: what the post quad leaves in the depth attachment
+constexpr uint64_t kOverlayClear = ((uint64_t)kOverlayBaseDepthBits << 32) | 0xFFFFFFFFull;
+
+TOPO_HD int overlay_vertex(const OverlayVertex& v, float width, float W, float H, SVert& s) {
+    const float z = div_f((float)v.z_index, 4096.0f);
+    const float px = v.position[0] + v.normal[0] * width, py = -(v.position[1] + v.normal[1] * width);
+    float clip[4] = {div_f(2.0f * px, W) - 1.0f, div_f(2.0f * py, H) + 1.0f, z, 1.0f};
+    if (!(z >= 0.0f)) clip[2] = 0.0f;      // (never: z_index >= 0; keeps clip_to_screen's near-plane flag out of it)
+    const int flag = clip_to_screen(clip, W, H, s);      // w = 1: the perspective divide is exact
+    s.z = z;
+    return flag;
+}
+// key of an overlay fragment: larger z wins (Greater), on equal z the EARLIER triangle (the later one fails the test)
+TOPO_HD uint64_t overlay_key(float z, uint32_t tri) { return ((uint64_t)f_bits(z) << 32) | (0xFFFFFFFFu - tri); }
+// colour of the fragment of triangle (v0, v1, v2) at pixel (px, py): varyings with w = 1 (Raster spec 8 with q_i = b_i)
+TOPO_HD bool overlay_color(const OverlayVertex& v0, const OverlayVertex& v1, const OverlayVertex& v2, float width, int32_t W, int32_t H,
+                           int32_t px, int32_t py, float rgb[3]) {
+    SVert s0, s1, s2;
+    if (overlay_vertex(v0, width, (float)W, (float)H, s0) != kVtxOk || overlay_vertex(v1, width, (float)W, (float)H, s1) != kVtxOk ||
+        overlay_vertex(v2, width, (float)W, (float)H, s2) != kVtxOk)
+        return false;
+    float b[3];
+    if (!triangle_bary(s0, s1, s2, px, py, b)) return false;
+    const float iq = div_f(1.0f, (b[0] + b[1]) + b[2]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) rgb[k] = fmaf(v2.color[k], b[2], fmaf(v1.color[k], b[1], v0.color[k] * b[0])) * iq;
+    return true;
+}
+
 // ---- peak visibility (render_engine.rs:338-396; glam Mat4::project_point3 + camera.rs:12-14) ---------------
 // This is CPU code in the reference (glam, SSE2: separate multiplies and adds, true divisions), restated as is.
 // Returns true when the peak projects inside the open NDC cube; then (x_pos, y_pos) is its pixel and peak_dist the
