@@ -56,7 +56,7 @@ def main():
                          "after the other (per-kernel durations are then those of the kernel alone); 2 overlaps consecutive "
                          "panoramas (profiles/: +18 %% throughput at c4)")
     ap.add_argument("--also-pipelined", action="store_true",
-                    help="after the timed region, also time the same panoramas with 2 frames in flight (reported under \"pipelined\")")
+                    help="after the timed region, also time the same panoramas with 2 frames in flight (reported under \"pipelined\", never `value`)")
     ap.add_argument("--pitch", type=float, default=0.0, help="camera pitch in radians (reference: positive looks down)")
     ap.add_argument("--host-path", action="store_true", help="also time topo_render (host outputs, PCIe-inclusive)")
     ap.add_argument("--no-pmc", action="store_true",
@@ -308,14 +308,14 @@ def main():
         "hbm_read_roofline_frac_frame": round((4.0 * n_tiles * TILE * TILE / (ms_per_step / 1e3) / 1e9) / HBM_PEAK_GBPS, 5),
         "counters": counters,
         "terrain_pixel_frac": round(float((depth < 1.0).float().mean().item()), 4),   # this rank's sectors
-        "host_cores": os.cpu_count(),
+        "host_cores": os.cpu_count(), "usable_cores": usable_cores(),
         "setup_s": round(setup_s, 1),
         "upload_s": round(upload_s, 2),
     }
 
     # ---- throughput mode (additive, never `value`): consecutive panoramas with two frames in flight, so that the
     # latency-bound cull/raster phases of one run under the ALU-bound resolve of the previous one
-    if world == 1 and args.also_pipelined:
+    if world == 1 and args.also_pipelined and depth_frames == 1:
         r.set_pipeline_depth(2)
         outs2 = outs + [(torch.empty_like(outs[0][0]), torch.empty_like(outs[0][1]))]
         def step2(i):
@@ -507,6 +507,25 @@ def _nearest_tiles(locs, vlat, vlon, k):
     return sorted(locs, key=lambda l: (l[0] + 0.5 - vlat) ** 2 + (l[1] + 0.5 - vlon) ** 2)[:k]
 
 
+def usable_cores():
+    """The cores this process may actually run on: the affinity mask, capped by the cgroup's CPU quota (a GPU box shows all
+    256 host cores but grants a share of them; more threads than that only slow the baseline down)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    n = min(n, max(1, q // int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())))
+        except (OSError, ValueError, IndexError):
+            pass
+    return n
+
+
 def cpu_baseline(T, np, locs, vlat, vlon, views, SW, PH, threads):
     """The oracle (kind "port": the reference's own wgpu CPU-adapter path cannot be built here) over the FULL workload -- one
     whole panorama -- on ALL host cores: with more cores than sectors each sector's tiles are split into runs of the draw
@@ -514,7 +533,7 @@ def cpu_baseline(T, np, locs, vlat, vlon, views, SW, PH, threads):
     same bytes).  Capped at 128 threads: 67 MB of z-buffer per job at c4."""
     from oracle import oracle as O
     host = os.cpu_count() or 1
-    cores = threads or min(host, 128)
+    cores = threads or min(usable_cores(), 128)
     groups = max(1, min(len(locs), (cores + N_SECTORS - 1) // N_SECTORS))
     sample = _nearest_tiles(locs, vlat, vlon, len(locs) if os.environ.get('TOPO_CPU_SAMPLE_TILES') is None else int(os.environ['TOPO_CPU_SAMPLE_TILES']))
     o = O.OracleRenderer(SW, PH)
@@ -524,7 +543,7 @@ def cpu_baseline(T, np, locs, vlat, vlon, views, SW, PH, threads):
     t0 = time.perf_counter()
     o.render_views_tiled(views, threads=cores, groups=groups)
     dt = time.perf_counter() - t0
-    return {"value": round(N_SECTORS * SW * PH / 1e6 / dt, 3), "unit": "Mpix/s", "cores": cores, "host_cores": host, "kind": "port",
+    return {"value": round(N_SECTORS * SW * PH / 1e6 / dt, 3), "unit": "Mpix/s", "cores": cores, "host_cores": host, "usable_cores": usable_cores(), "kind": "port",
             "seconds": round(dt, 2),
             "sample": f"one full panorama: all 8 sectors at full size ({N_SECTORS * SW}x{PH}) over {len(sample)} of the {len(locs)} tiles; "
                       f"oracle/topo_oracle.cpp, {cores} OpenMP threads over {N_SECTORS} sectors x {groups} runs of tiles"}

@@ -12,7 +12,7 @@ mkdir -p $O
 for w in c1 c2 c3; do
   timeout -k 10 300 python3 bench.py --workload $w --no-cpu-baseline --no-pmc > $O/bench_$w.json 2> $O/bench_$w.err; echo "$w done"
 done
-timeout -k 10 900 python3 bench.py --workload c4 --check > $O/bench_c4.json 2> $O/bench_c4.err; echo "c4 done"
+timeout -k 10 900 python3 bench.py --workload c4 --check --also-pipelined > $O/bench_c4.json 2> $O/bench_c4.err; echo "c4 done"
 timeout -k 10 300 python3 bench.py --workload c4 --pipeline 2 --steps 20 --no-cpu-baseline --no-pmc > $O/bench_c4_pipelined.json 2> $O/bench_c4_pipelined.err; echo "c4 pipelined done"
 timeout -k 10 400 python3 bench.py --workload c5 --no-cpu-baseline --no-pmc --steps 2 --warmup 1 > $O/bench_c5.json 2> $O/bench_c5.err; echo "c5 done"
 cd /tmp && export TMPDIR=/tmp
