@@ -164,6 +164,29 @@ VALU_KERNEL(v_lshl, A_LSHL, uint32_t)
 VALU_KERNEL(v_and, A_AND, uint32_t)
 VALU_KERNEL(v_add64, A_ADD64, uint32_t)
 
+// packed f32 (two f32 operations per lane and instruction, operands in aligned register pairs)
+typedef float v2f __attribute__((ext_vector_type(2)));
+#define A_PKMUL(k) "v_pk_mul_f32 %" #k ", %8, %" #k
+#define A_PKADD(k) "v_pk_add_f32 %" #k ", %8, %" #k
+#define PK_KERNEL(NAME, ASM)                                                                                           \
+    __global__ __launch_bounds__(256) void NAME(Stamp* __restrict__ st, float xs, float ys, float* __restrict__ out) { \
+        v2f r[8];                                                                                                      \
+        const v2f x = {xs, xs * 1.5f}, y = {ys, ys * 0.5f};                                                            \
+        for (int k = 0; k < 8; ++k) r[k] = v2f{xs + (float)(threadIdx.x + k), xs - (float)k};                           \
+        __syncthreads();                                                                                               \
+        const uint64_t t0 = __builtin_amdgcn_s_memtime();                                                              \
+        STREAM8(ASM)                                                                                                   \
+        asm volatile("s_nop 0" ::: "memory");                                                                          \
+        const uint64_t t1 = __builtin_amdgcn_s_memtime();                                                              \
+        float acc = 0.0f;                                                                                              \
+        for (int k = 0; k < 8; ++k) acc += r[k].x + r[k].y;                                                            \
+        if ((threadIdx.x & 63) == 0) st[blockIdx.x * 4 + (threadIdx.x >> 6)] = Stamp{t0, t1};                          \
+        if (acc == 12345.0f) out[0] = acc;                                                                             \
+    }
+PK_KERNEL(v_pkfma, A_PKFMA)
+PK_KERNEL(v_pkmul, A_PKMUL)
+PK_KERNEL(v_pkadd, A_PKADD)
+
 template <typename K, typename T>
 static void time_valu(const char* name, K kernel, T x, T y, int insts_per_slot, std::string& json) {
     int cus = 0;
@@ -233,6 +256,9 @@ static void run_valu() {
     time_valu("v_lshlrev_b32", v_lshl, 3u, 5u, 1, j);
     time_valu("v_and_b32", v_and, 3u, 5u, 1, j);
     time_valu("v_add_co+v_addc (64-bit add)", v_add64, 3u, 5u, 2, j);
+    time_valu("v_pk_fma_f32", v_pkfma, 1.0001f, 0.5f, 1, j);
+    time_valu("v_pk_mul_f32", v_pkmul, 1.0001f, 0.5f, 1, j);
+    time_valu("v_pk_add_f32", v_pkadd, 1.0001f, 0.5f, 1, j);
     int clk = 0;
     CK(hipDeviceGetAttribute(&clk, hipDeviceAttributeClockRate, 0));
     printf("{\"valu_issue_cost\": {%s}, \"unit\": \"cyc_*: s_memtime ticks, ns_*: HIP-event wall time (incl. ~10 us of launch), per wave64 instruction per SIMD\", \"clock_rate_khz\": %d}\n", j.c_str(), clk);
