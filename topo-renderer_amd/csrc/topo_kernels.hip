@@ -934,11 +934,12 @@ __device__ __forceinline__ ResolveBlock resolve_block(const FrameParams& P, uint
     const uint32_t row = P.rblocks_x > 1u ? fastdiv(in_view, P.div_rblocks_x) : in_view;
     return ResolveBlock{view, (int32_t)(in_view - row * P.rblocks_x) * 64, (int32_t)row * kResolveRows};
 }
-// Did anything write a key of the block or its halo?  Every row of block + halo spans at most three 64-key segments;
-// t < 54 names one (row, segment) mark.
-__device__ __forceinline__ bool resolve_block_marked(const FrameParams& P, const ResolveBlock& B, uint32_t t) {
+// Did anything write a key of wave `wave`'s strip (rows 4 wave .. 4 wave + 3 of the block) or its halo?  Every row of strip +
+// halo spans at most three 64-key segments; t < 18 names one (row, segment) mark.
+constexpr uint32_t kStripMarks = (kRPW + 2) * 3;
+__device__ __forceinline__ bool resolve_strip_marked(const FrameParams& P, const ResolveBlock& B, uint32_t wave, uint32_t t) {
     const int32_t row = (int32_t)t / 3, k = (int32_t)t - row * 3;
-    int32_t y = B.by + row - 1;
+    int32_t y = B.by + kRPW * (int32_t)wave + row - 1;
     y = y < 0 ? 0 : (y > P.H - 1 ? P.H - 1 : y);
     const int32_t x0 = B.bx > 0 ? B.bx - 1 : 0, x1 = B.bx + 64 < P.W ? B.bx + 64 : P.W - 1;
     const size_t first = (size_t)B.view * P.W * P.H + (size_t)y * P.W;
@@ -948,37 +949,47 @@ __device__ __forceinline__ bool resolve_block_marked(const FrameParams& P, const
     const bool mark = TOPO_CHK(P.counters, at < (((size_t)P.n_views * P.W * P.H + 63) >> 6), 12u, at) ? P.dirty[at] != 0 : false;
     return seg <= last && mark;
 }
-struct ResolveKeys {           // what a thread holds of a block: the keys of its own four pixels and (threads < 164) one ring key
+// What a lane holds of a strip: the keys of its own four pixels and up to three depths of the ring around the strip
+// (entry e = lane + 64 k of: row -1 (66 entries), row 4 (66), columns -1 and 64 of rows 0..3 (8)).
+struct ResolveKeys {
     Row4<uint32_t> id, raw;
-    uint32_t ring_hi;
+    uint32_t ring0, ring1, ring2;
 };
+constexpr uint32_t kRingEntries = 2 * 66 + 2 * kRPW;
+__device__ __forceinline__ void resolve_ring_pos(uint32_t e, int32_t& ly, int32_t& lx) {      // tile position (row 0..5, column 0..65) of ring entry e
+    if (e < 66u) { ly = 0; lx = (int32_t)e; }
+    else if (e < 132u) { ly = kRPW + 1; lx = (int32_t)e - 66; }
+    else { const int32_t k = (int32_t)(e < kRingEntries ? e : kRingEntries - 1u) - 132; ly = 1 + (k >> 1); lx = (k & 1) ? 65 : 0; }
+}
 __device__ __forceinline__ void resolve_load_keys(const FrameParams& P, const ResolveBlock& B, uint32_t lane, uint32_t wave, ResolveKeys& K) {
     const uint64_t* vis = P.vis + (size_t)B.view * P.W * P.H;
-    const int32_t px = B.bx + (int32_t)lane;
+    const int32_t px = B.bx + (int32_t)lane, sy = B.by + kRPW * (int32_t)wave;
     // (outside the target the positions clamp to the edge; those lanes / rows only feed the contour taps' LDS tile)
     const int32_t cx = px > P.W - 1 ? P.W - 1 : px;
 #define TOPO_X(r, m)                                                                  \
     {                                                                                 \
-        const int32_t py = B.by + (int32_t)wave + 4 * r;                              \
+        const int32_t py = sy + r;                                                    \
         const uint64_t key = vis[(size_t)(py > P.H - 1 ? P.H - 1 : py) * P.W + cx];   \
         K.id.m = (uint32_t)key;                                                       \
         K.raw.m = (uint32_t)(key >> 32);                                              \
     }
     TOPO_ROWS4(TOPO_X)
 #undef TOPO_X
-    K.ring_hi = 0x3F800000u;
-    if (threadIdx.x < 2 * 66 + 2 * kResolveRows) {      // the ring: rows -1 and 16 (66 entries each), columns -1 and 64 of rows 0..15
-        int32_t ly, lx;
-        if (threadIdx.x < 132) { ly = threadIdx.x < 66 ? 0 : kResolveRows + 1; lx = (int32_t)threadIdx.x % 66; }
-        else { const int32_t k = (int32_t)threadIdx.x - 132; ly = 1 + (k >> 1); lx = (k & 1) ? 65 : 0; }
-        int32_t x = B.bx + lx - 1, y = B.by + ly - 1;
-        x = x < 0 ? 0 : (x > P.W - 1 ? P.W - 1 : x);   // clamp-to-edge depth sampler (texture.rs:113-117)
-        y = y < 0 ? 0 : (y > P.H - 1 ? P.H - 1 : y);
-        K.ring_hi = (uint32_t)(vis[(size_t)y * P.W + x] >> 32);
+    // the ring: depth words only; every lane loads three (clamped positions: no branches around the loads)
+#define TOPO_RING(k, m)                                                                        \
+    {                                                                                          \
+        int32_t ly, lx;                                                                        \
+        resolve_ring_pos(lane + 64u * k, ly, lx);                                              \
+        int32_t x = B.bx + lx - 1, y = sy + ly - 1;                                            \
+        x = x < 0 ? 0 : (x > P.W - 1 ? P.W - 1 : x);   /* clamp-to-edge depth sampler (texture.rs:113-117) */ \
+        y = y < 0 ? 0 : (y > P.H - 1 ? P.H - 1 : y);                                           \
+        K.m = reinterpret_cast<const uint32_t*>(vis + (size_t)y * P.W + x)[1];                 \
     }
+    TOPO_RING(0u, ring0)
+    TOPO_RING(1u, ring1)
+    TOPO_RING(2u, ring2)
+#undef TOPO_RING
 }
-
-constexpr uint32_t kResolveChunk = 512;      // blocks of one workgroup whose marks are looked at in one go
 
 __device__ __forceinline__ void resolve_fill_sky(const FrameParams& P, const OutputParams& O, const ResolveBlock& B, uint32_t lane, uint32_t wave) {
     const int32_t px = B.bx + (int32_t)lane;
@@ -986,23 +997,29 @@ __device__ __forceinline__ void resolve_fill_sky(const FrameParams& P, const Out
     uint8_t* const rgba_col = O.rgba + (size_t)B.view * O.rgba_view_stride + (size_t)px * 4;
     uint8_t* const depth_col = O.depth ? reinterpret_cast<uint8_t*>(O.depth) + (size_t)B.view * O.depth_view_stride + (size_t)px * 4 : nullptr;
     const uint32_t sky = P.bgra ? (P.sky_c8 & 0xFF00FF00u) | ((P.sky_c8 >> 16) & 0xFFu) | ((P.sky_c8 & 0xFFu) << 16) : P.sky_c8;
-    for (int32_t ty = (int32_t)wave; ty < kResolveRows && B.by + ty < P.H; ty += 4) {
+    for (int32_t ty = kRPW * (int32_t)wave; ty < kRPW * ((int32_t)wave + 1) && B.by + ty < P.H; ++ty) {
         *reinterpret_cast<uint32_t*>(rgba_col + (size_t)(B.by + ty) * O.rgba_pitch) = sky;
         if (depth_col) *reinterpret_cast<float*>(depth_col + (size_t)(B.by + ty) * O.depth_pitch) = 1.0f;
     }
 }
+__device__ __forceinline__ uint32_t pop_bit(uint64_t& m) {      // wave-uniform mask: scalar instructions
+    const uint32_t j = (uint32_t)__builtin_ctzll(m);
+    m &= m - 1ull;
+    return j;
+}
 
+// The four waves of a workgroup share the tables and the list of 64 x 16 blocks, and nothing else: wave w takes rows
+// 4w .. 4w+3 of every block (a 64 x 4 strip) with its own halo, its own depth tile and its own record table, at its own pace --
+// no barrier after the tables are in place.  (With one depth tile per block, two barriers per block made every wave wait for the
+// block's slowest: 29 % of all wave time.)
 __global__ __launch_bounds__(256, TOPO_RESOLVE_WGS) void k_resolve(FrameParams P, OutputParams O) {
     __shared__ float s_thresh[258];    // sRGB code boundaries; [255..257] = NaN: never <= anything (srgb_encode_lut probes up to 256)
     __shared__ float s_decode[256];
     __shared__ float s_ndec[256];      // normal channel decode 2c/255 - 1
     __shared__ uint32_t s_lut[1024];   // 4096 one-byte bins of srgb_encode_lut
-    __shared__ float s_lin[kResolveRows + 2][66];            // linear depth of the block + halo
+    __shared__ float s_lin[4][kRPW + 2][66];                 // per wave: linear depth of the strip + halo
     __shared__ uint32_t s_rec[4][kTriRecordWords][kRecCap];  // per wave: the records, word-major (lanes with consecutive slots hit consecutive banks)
     __shared__ uint32_t s_uid[4][kRecCap];                   // per wave: the distinct winner ids
-    __shared__ uint8_t s_flag[kResolveChunk];                // this chunk's blocks: was anything drawn in the block or its halo
-    __shared__ uint16_t s_marked[kResolveChunk], s_clear[kResolveChunk];      // ... sorted into the two work lists
-    __shared__ uint32_t s_count[2];
     const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int32_t tx = (int32_t)lane;
     // Blocks are dealt out with a static stride: workgroup g takes blocks g, g + grid, g + 2 grid, ... -- a sample of every
@@ -1019,6 +1036,7 @@ __global__ __launch_bounds__(256, TOPO_RESOLVE_WGS) void k_resolve(FrameParams P
 #pragma unroll
     for (int k = 0; k < 4; ++k) s_lut[threadIdx.x + 256 * k] = TOPO_SRGB_LUT12_WORDS[threadIdx.x + 256 * k];
     const uint8_t* lut = reinterpret_cast<const uint8_t*>(s_lut);
+    __syncthreads();                   // the only barrier
 #ifdef TOPO_RESOLVE_PROF      // experiment build: where do a wave's cycles go?  counters[8..15], units of 1024 cycles summed over waves
     uint32_t pf_t = (uint32_t)__builtin_amdgcn_s_memtime(), pf_acc[7] = {0, 0, 0, 0, 0, 0, 0};
     const uint32_t pf_start = pf_t;
@@ -1026,87 +1044,75 @@ __global__ __launch_bounds__(256, TOPO_RESOLVE_WGS) void k_resolve(FrameParams P
 #else
 #define TOPO_PROF(slot)
 #endif
+    float (*const lin_tile)[66] = s_lin[wave];
+    const int32_t sy0 = kRPW * (int32_t)wave;      // the strip's first row within its block
 
-    for (uint32_t j0 = 0; j0 < per_wg; j0 += kResolveChunk) {
-        const uint32_t nj = per_wg - j0 < kResolveChunk ? per_wg - j0 : kResolveChunk;
-        // ---- which of this chunk's blocks hold anything: all their segment marks in one trip to memory
-        __syncthreads();      // (the previous chunk's lists are done with)
-        for (uint32_t j = threadIdx.x; j < nj; j += 256) s_flag[j] = 0;
-        __syncthreads();
-        constexpr uint32_t kMarks = (kResolveRows + 2) * 3;
-        for (uint32_t q0 = 0; q0 < nj * kMarks; q0 += 256 * 8) {      // eight marks per thread in flight at a time
-            bool m[8];
-            uint32_t jj[8];
+    for (uint32_t j0 = 0; j0 < per_wg; j0 += 64) {
+        const uint32_t nj = per_wg - j0 < 64u ? per_wg - j0 : 64u;
+        // ---- which of these blocks' strips hold anything: lane j looks at block j0 + j, all its marks in one trip to memory
+        uint64_t mm, mc;       // strips with / without anything drawn
+        {
+            const ResolveBlock Bl = resolve_block(P, blockIdx.x + (j0 + (lane < nj ? lane : 0u)) * stride);
+            bool any = false;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const uint32_t q = q0 + (uint32_t)u * 256 + threadIdx.x;
-                const uint32_t qq = q < nj * kMarks ? q : 0u;      // (clamped, not skipped: the eight loads must not be chained by branches)
-                jj[u] = qq / kMarks;
-                m[u] = resolve_block_marked(P, resolve_block(P, blockIdx.x + (j0 + jj[u]) * stride), qq - jj[u] * kMarks) && q < nj * kMarks;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (m[u]) s_flag[jj[u]] = 1;      // racing writers agree
+            for (uint32_t t = 0; t < kStripMarks; ++t) any |= resolve_strip_marked(P, Bl, wave, t);      // (unconditional loads, none chained to another)
+            const bool exists = lane < nj && Bl.by + sy0 < P.H;
+            mm = __ballot(exists && any);
+            mc = __ballot(exists && !any);
         }
-        __syncthreads();
-        if (wave == 0) {      // the two work lists, in block order
-            uint32_t nm = 0, nc = 0;
-            for (uint32_t j = 0; j < nj; j += 64) {
-                const bool in = j + lane < nj, m = in && s_flag[j + lane] != 0;
-                const uint64_t mm = __ballot(m), mc = __ballot(in && !m), lt = (1ull << lane) - 1ull;
-                if (m) s_marked[nm + (uint32_t)__popcll(mm & lt)] = (uint16_t)(j + lane);
-                else if (in) s_clear[nc + (uint32_t)__popcll(mc & lt)] = (uint16_t)(j + lane);
-                nm += (uint32_t)__popcll(mm);
-                nc += (uint32_t)__popcll(mc);
-            }
-            if (lane == 0) { s_count[0] = nm; s_count[1] = nc; }
-        }
-        __syncthreads();
-        const uint32_t n_marked = s_count[0], n_clear = s_count[1];
-        TOPO_PROF(0)      // marks + lists
-        // (the list entries come out of LDS: tell the compiler they are wave-uniform, or every address derived from a
-        // block's origin becomes per-lane arithmetic and every load of its view's constants a vector load)
-        auto block_of = [&](uint32_t j) { return resolve_block(P, blockIdx.x + (j0 + uni(j)) * stride); };
-        // the untouched blocks are pure stores: spread over the marked blocks' iterations, so that their bandwidth hides
+        const uint32_t n_marked = (uint32_t)__popcll(mm), n_clear = (uint32_t)__popcll(mc);
+        TOPO_PROF(0)      // marks
+        auto block_of = [&](uint32_t j) { return resolve_block(P, blockIdx.x + (j0 + j) * stride); };      // (j comes out of a wave-uniform mask)
+        // the untouched strips are pure stores: spread over the marked strips' iterations, so that their bandwidth hides
         // under the shading
         const uint32_t fills_per_iter = n_marked ? (n_clear + n_marked - 1) / n_marked : n_clear;
-        uint32_t ci = 0;
         ResolveKeys K;
-        if (n_marked) resolve_load_keys(P, block_of(s_marked[0]), lane, wave, K);
+        uint32_t j_next = 0;
+        if (mm) { j_next = pop_bit(mm); resolve_load_keys(P, block_of(j_next), lane, wave, K); }
         for (uint32_t i = 0; i < (n_marked ? n_marked : 1u); ++i) {
             ResolveKeys Kn;
-            if (i + 1 < n_marked) resolve_load_keys(P, block_of(s_marked[i + 1]), lane, wave, Kn);      // in flight while block i is shaded
-            for (uint32_t f = 0; f < fills_per_iter && ci < n_clear; ++f, ++ci) resolve_fill_sky(P, O, block_of(s_clear[ci]), lane, wave);
+            const uint32_t j_cur = j_next;
+            if (mm) { j_next = pop_bit(mm); resolve_load_keys(P, block_of(j_next), lane, wave, Kn); }      // in flight while strip i is shaded
+            for (uint32_t f = 0; f < fills_per_iter && mc; ++f) resolve_fill_sky(P, O, block_of(pop_bit(mc)), lane, wave);
             TOPO_PROF(1)  // issue of the next keys + sky fills
             if (i >= n_marked) break;
-            const ResolveBlock B = block_of(s_marked[i]);
+            const ResolveBlock B = block_of(j_cur);
             const int32_t px = B.bx + tx;
             const bool in_x = px < P.W;        // lanes beyond the target's right edge stay: they compute triangle records
             uint8_t* const rgba_col = O.rgba + (size_t)B.view * O.rgba_view_stride + (size_t)px * 4;
             uint8_t* const depth_col = O.depth ? reinterpret_cast<uint8_t*>(O.depth) + (size_t)B.view * O.depth_view_stride + (size_t)px * 4 : nullptr;
             const Row4<uint32_t> ids = K.id, raws = K.raw;
-            const bool terrain = raws.a != 0x3F800000u || raws.b != 0x3F800000u || raws.c != 0x3F800000u || raws.d != 0x3F800000u || K.ring_hi != 0x3F800000u;
-            TOPO_PROF(2)  // wait for this block's keys
-            __syncthreads();                    // every wave is done with the previous block's linear depths
-            TOPO_PROF(3)  // barrier: the slowest wave of the previous block
-#define TOPO_X(r, m) s_lin[(int32_t)wave + 4 * r + 1][tx + 1] = linear_depth(bits_f(raws.m));
+            const bool terrain = raws.a != 0x3F800000u || raws.b != 0x3F800000u || raws.c != 0x3F800000u || raws.d != 0x3F800000u ||
+                                 K.ring0 != 0x3F800000u || K.ring1 != 0x3F800000u || (lane + 128u < kRingEntries && K.ring2 != 0x3F800000u);
+            TOPO_PROF(2)  // wait for this strip's keys
+            // (the tile is written and read by this wave alone: the LDS operations of one wave complete in order)
+#define TOPO_X(r, m) lin_tile[r + 1][tx + 1] = linear_depth(bits_f(raws.m));
             TOPO_ROWS4(TOPO_X)
 #undef TOPO_X
-            if (threadIdx.x < 2 * 66 + 2 * kResolveRows) {
+            {
                 int32_t ly, lx;
-                if (threadIdx.x < 132) { ly = threadIdx.x < 66 ? 0 : kResolveRows + 1; lx = (int32_t)threadIdx.x % 66; }
-                else { const int32_t k = (int32_t)threadIdx.x - 132; ly = 1 + (k >> 1); lx = (k & 1) ? 65 : 0; }
-                s_lin[ly][lx] = linear_depth(bits_f(K.ring_hi));
+                resolve_ring_pos(lane, ly, lx);
+                lin_tile[ly][lx] = linear_depth(bits_f(K.ring0));
+                resolve_ring_pos(lane + 64u, ly, lx);
+                lin_tile[ly][lx] = linear_depth(bits_f(K.ring1));
+                resolve_ring_pos(lane + 128u, ly, lx);
+                if (lane + 128u < kRingEntries) lin_tile[ly][lx] = linear_depth(bits_f(K.ring2));
             }
-            const bool any_terrain = __syncthreads_or(terrain) != 0;      // also publishes s_lin
-            TOPO_PROF(4)  // linear depths + barrier
+            const bool any_terrain = __ballot(terrain) != 0ull;
+            TOPO_PROF(4)  // linear depths
+            // the depth output is the key's depth word: stored now, so that the four words are not held through the shading
+            if (any_terrain && in_x && depth_col) {
+#define TOPO_X(r, m) if (B.by + sy0 + r < P.H) *reinterpret_cast<uint32_t*>(depth_col + (size_t)(B.by + sy0 + r) * O.depth_pitch) = raws.m;
+                TOPO_ROWS4(TOPO_X)
+#undef TOPO_X
+            }
             if (!any_terrain) {                // marked, but every key still cleared (a mark covers 64 keys): the cleared texel and depth 1
                 resolve_fill_sky(P, O, B, lane, wave);
                 K = Kn;
                 continue;
             }
             const ViewDev& view = P.views[B.view];
-            // what fs_main reads of the view, once per block and wave-uniform: left to the compiler these are re-loaded in every
+            // what fs_main reads of the view, once per strip and wave-uniform: left to the compiler these are re-loaded in every
             // row (it cannot prove the output stores do not alias them) behind an s_waitcnt vmcnt(0) that also waits for the
             // previous row's stores to land
             const f3 sun = {unif(view.sun[0]), unif(view.sun[1]), unif(view.sun[2])};
@@ -1120,7 +1126,7 @@ __global__ __launch_bounds__(256, TOPO_RESOLVE_WGS) void k_resolve(FrameParams P
                 uint32_t n = 0;
 #define TOPO_X(r, m)                                                                                                                   \
     {                                                                                                                                  \
-        const bool valid = in_x && B.by + (int32_t)wave + 4 * r < P.H && ids.m != kNoTri;                                              \
+        const bool valid = in_x && B.by + sy0 + r < P.H && ids.m != kNoTri;                                                            \
         const uint32_t left = (uint32_t)__shfl_up((int)ids.m, 1);                                                                      \
         const bool leader = valid && (lane == 0 || ids.m != left);                                                                     \
         const uint64_t mask = __ballot(leader);                                                                                        \
@@ -1182,10 +1188,10 @@ __global__ __launch_bounds__(256, TOPO_RESOLVE_WGS) void k_resolve(FrameParams P
                 // (the table is written and read by the same wave: the LDS operations of one wave complete in order)
 #pragma unroll 1
                 for (int32_t r = r0; r < r1; ++r) {
-                    const int32_t ty = (int32_t)wave + 4 * r, py = B.by + ty;
+                    const int32_t ty = sy0 + r, py = B.by + ty;
                     if (py >= P.H) break;
                     // (r is wave-uniform: pick() is scalar-conditioned moves)
-                    const uint32_t id_r = ids.pick(r), raw_r = raws.pick(r), sl = slot.pick(r) - gbase;
+                    const uint32_t id_r = ids.pick(r), sl = slot.pick(r) - gbase;
                     const uint32_t id = in_x ? id_r : kNoTri;
                     // the contour taps first: they depend on nothing, so their LDS trip overlaps the record's
                     float ln[8];
@@ -1196,10 +1202,10 @@ __global__ __launch_bounds__(256, TOPO_RESOLVE_WGS) void k_resolve(FrameParams P
 #pragma unroll
                             for (int j = -1; j <= 1; ++j) {
                                 if (i == 0 && j == 0) continue;
-                                ln[k++] = s_lin[ty + 1 + j][tx + 1 + i];
+                                ln[k++] = lin_tile[r + 1 + j][tx + 1 + i];
                             }
                     }
-                    const float lin_c = s_lin[ty + 1][tx + 1];
+                    const float lin_c = lin_tile[r + 1][tx + 1];
                     // render target texel (Rgba8UnormSrgb): the cleared value or the shaded winner
                     uint32_t c8 = P.sky_c8;
                     if (id != kNoTri) {
@@ -1225,10 +1231,7 @@ __global__ __launch_bounds__(256, TOPO_RESOLVE_WGS) void k_resolve(FrameParams P
                     }
                     uint32_t out = post_pixel_t<true>(s_thresh, s_decode, c8, lin_c, ln, lut, P.linear_target == 0u);
                     if (P.bgra) out = (out & 0xFF00FF00u) | ((out >> 16) & 0xFFu) | ((out & 0xFFu) << 16);
-                    if (in_x) {
-                        *reinterpret_cast<uint32_t*>(rgba_col + (size_t)py * O.rgba_pitch) = out;
-                        if (depth_col) *reinterpret_cast<uint32_t*>(depth_col + (size_t)py * O.depth_pitch) = raw_r;
-                    }
+                    if (in_x) *reinterpret_cast<uint32_t*>(rgba_col + (size_t)py * O.rgba_pitch) = out;
                 }
                 TOPO_PROF(6)  // pixels
                 gbase += cnt;
@@ -1236,7 +1239,7 @@ __global__ __launch_bounds__(256, TOPO_RESOLVE_WGS) void k_resolve(FrameParams P
             }
             K = Kn;
         }
-        for (; ci < n_clear; ++ci) resolve_fill_sky(P, O, block_of(s_clear[ci]), lane, wave);
+        while (mc) resolve_fill_sky(P, O, block_of(pop_bit(mc)), lane, wave);
         TOPO_PROF(1)
     }
 #ifdef TOPO_RESOLVE_PROF
