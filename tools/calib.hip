@@ -60,6 +60,50 @@ __global__ __launch_bounds__(256) void cal_atomic8(uint64_t* __restrict__ out, s
         atomicMin(reinterpret_cast<unsigned long long*>(out + i), (unsigned long long)(v + i));
 }
 
+// 64-bit atomic min where one wave instruction covers ROWS rows of 64/ROWS keys (row pitch 2048 keys = 16 KiB): how does the
+// rate depend on the shape of the 512 bytes a wave touches?  (k_raster_big's giant path: 8 x 8 px chunks = 8 rows of 64 B)
+template <int ROWS>
+__global__ __launch_bounds__(256) void cal_atomic8_shape(uint64_t* __restrict__ out, uint64_t v) {
+    constexpr int COLS = 64 / ROWS;
+    const uint32_t lane = threadIdx.x & 63;
+    const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwave = (size_t)gridDim.x * 4;
+    // the buffer as a 2048-key-wide image of 65536 rows (1 GiB); tiles of ROWS x COLS keys, row-major over the image
+    const size_t tiles_x = 2048 / COLS, n_tiles = tiles_x * (65536 / ROWS);
+    for (size_t t = wave; t < n_tiles; t += nwave) {
+        const size_t ty = t / tiles_x, tx = t - ty * tiles_x;
+        const size_t at = (ty * ROWS + lane / COLS) * 2048 + tx * COLS + lane % COLS;
+        atomicMin(reinterpret_cast<unsigned long long*>(out + at), (unsigned long long)(v + at));
+    }
+}
+static void run_atomic_shapes() {
+    const size_t bytes = (size_t)1 << 30;
+    void* b = nullptr;
+    CK(hipMalloc(&b, bytes));
+    CK(hipMemset(b, 0xFF, bytes));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    printf("{\"atomic_min_u64_shapes\": {");
+    auto run = [&](const char* name, auto kern, bool last) {
+        float best = 1e9f;
+        for (int r = 0; r < 3; ++r) {
+            CK(hipEventRecord(e0, 0));
+            hipLaunchKernelGGL(kern, dim3(8192), dim3(256), 0, 0, (uint64_t*)b, 7ull);
+            CK(hipEventRecord(e1, 0));
+            CK(hipDeviceSynchronize());
+            float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+            best = ms < best ? ms : best;
+        }
+        printf("\"%s\": {\"ms_per_GiB\": %.4f, \"G_keys_per_s\": %.2f}%s", name, best, (double)(bytes / 8) / best / 1e6, last ? "" : ", ");
+    };
+    run("1x64 (512 B run)", cal_atomic8_shape<1>, false);
+    run("2x32 (256 B runs)", cal_atomic8_shape<2>, false);
+    run("4x16 (128 B runs)", cal_atomic8_shape<4>, false);
+    run("8x8 (64 B runs)", cal_atomic8_shape<8>, false);
+    run("16x4 (32 B runs)", cal_atomic8_shape<16>, true);
+    printf("}}\n");
+    CK(hipFree(b));
+}
+
 static void run_hbm() {
     const size_t bytes = (size_t)1 << 30;      // 1 GiB: four times the 256 MiB Infinity Cache
     void *a = nullptr, *b = nullptr;
@@ -187,6 +231,93 @@ PK_KERNEL(v_pkfma, A_PKFMA)
 PK_KERNEL(v_pkmul, A_PKMUL)
 PK_KERNEL(v_pkadd, A_PKADD)
 
+// 64-bit integer forms (register pairs): what the int64 edge functions of k_raster_big's giant path compile to
+typedef uint64_t u64;
+#define A_LSHLADD64(k) "v_lshl_add_u64 %" #k ", %" #k ", 0, %8"
+#define A_MAD64(k) "v_mad_u64_u32 %" #k ", vcc, %10, %11, %" #k
+#define A_CMP64(k) "v_cmp_lt_i64 vcc, %8, %" #k
+#define A_SHL64(k) "v_lshlrev_b64 %" #k ", 1, %" #k
+#define I64_KERNEL(NAME, ASM)                                                                                          \
+    __global__ __launch_bounds__(256) void NAME(Stamp* __restrict__ st, uint32_t xs, uint32_t ys, uint32_t* __restrict__ out) { \
+        u64 r[8];                                                                                                      \
+        const u64 x = ((u64)xs << 32) | ys, y = ((u64)ys << 20) | xs;                                                  \
+        const uint32_t a = xs + threadIdx.x, b = ys | 1u;                                                              \
+        for (int k = 0; k < 8; ++k) r[k] = x + (u64)(threadIdx.x + k) * 0x100000001ull;                                \
+        __syncthreads();                                                                                               \
+        const uint64_t t0 = __builtin_amdgcn_s_memtime();                                                              \
+        for (int it = 0; it < kIters; ++it) {                                                                          \
+            asm volatile(ASM(0) "\n" ASM(1) "\n" ASM(2) "\n" ASM(3) "\n" ASM(4) "\n" ASM(5) "\n" ASM(6) "\n" ASM(7)      \
+                         : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])  \
+                         : "v"(x), "v"(y), "v"(a), "v"(b) : "vcc");                                                    \
+        }                                                                                                              \
+        asm volatile("s_nop 0" ::: "memory");                                                                          \
+        const uint64_t t1 = __builtin_amdgcn_s_memtime();                                                              \
+        u64 acc = 0;                                                                                                   \
+        for (int k = 0; k < 8; ++k) acc += r[k];                                                                       \
+        if ((threadIdx.x & 63) == 0) st[blockIdx.x * 4 + (threadIdx.x >> 6)] = Stamp{t0, t1};                          \
+        if (acc == 12345ull) out[0] = (uint32_t)acc;                                                                   \
+    }
+// scalar unit: the same stream shape on SGPRs (one scalar ALU serves the CU's four SIMDs)
+#define S_ADD(k) "s_add_u32 %" #k ", %" #k ", %8"
+#define S_MUL(k) "s_mul_i32 %" #k ", %" #k ", %8"
+#define S_MULHI(k) "s_mul_hi_u32 %" #k ", %" #k ", %8"
+#define S_AND64(k) "s_and_b64 vcc, exec, vcc\ns_add_u32 %" #k ", %" #k ", %8"
+#define S_CSEL(k) "s_cmp_lt_u32 %" #k ", %9\ns_cselect_b32 %" #k ", %8, %" #k
+#define S_BR(k) "s_cmp_lt_u32 %" #k ", %9\ns_cbranch_scc1 1f\ns_add_u32 %" #k ", %" #k ", %8\n1:"
+#define SALU_KERNEL(NAME, ASM)                                                                                         \
+    __global__ __launch_bounds__(256) void NAME(Stamp* __restrict__ st, uint32_t xs, uint32_t ys, uint32_t* __restrict__ out) { \
+        uint32_t r[8];                                                                                                 \
+        for (int k = 0; k < 8; ++k) r[k] = __builtin_amdgcn_readfirstlane(xs + (threadIdx.x >> 6) + k);                \
+        const uint32_t x = __builtin_amdgcn_readfirstlane(xs | 1u), y = __builtin_amdgcn_readfirstlane(ys);            \
+        __syncthreads();                                                                                               \
+        const uint64_t t0 = __builtin_amdgcn_s_memtime();                                                              \
+        for (int it = 0; it < kIters; ++it) {                                                                          \
+            asm volatile(ASM(0) "\n" ASM(1) "\n" ASM(2) "\n" ASM(3) "\n" ASM(4) "\n" ASM(5) "\n" ASM(6) "\n" ASM(7)      \
+                         : "+s"(r[0]), "+s"(r[1]), "+s"(r[2]), "+s"(r[3]), "+s"(r[4]), "+s"(r[5]), "+s"(r[6]), "+s"(r[7])  \
+                         : "s"(x), "s"(y) : "vcc", "scc");                                                             \
+        }                                                                                                              \
+        asm volatile("s_nop 0" ::: "memory");                                                                          \
+        const uint64_t t1 = __builtin_amdgcn_s_memtime();                                                              \
+        uint32_t acc = 0;                                                                                              \
+        for (int k = 0; k < 8; ++k) acc += r[k];                                                                       \
+        if ((threadIdx.x & 63) == 0) st[blockIdx.x * 4 + (threadIdx.x >> 6)] = Stamp{t0, t1};                          \
+        if (acc == 12345u) out[0] = acc;                                                                               \
+    }
+SALU_KERNEL(s_add, S_ADD)
+SALU_KERNEL(s_mul, S_MUL)
+SALU_KERNEL(s_mulhi, S_MULHI)
+SALU_KERNEL(s_and64_add, S_AND64)
+SALU_KERNEL(s_cmp_csel, S_CSEL)
+SALU_KERNEL(s_cmp_br_add, S_BR)
+// do vector and scalar instructions of different waves share the SIMD's issue?  8 v_fma_f32 + 8 s_add_u32 per iteration
+__global__ __launch_bounds__(256) void mix_valu_salu(Stamp* __restrict__ st, float xf, float yf, float* __restrict__ out) {
+    float r[8];
+    uint32_t q[8];
+    for (int k = 0; k < 8; ++k) { r[k] = xf + (float)(threadIdx.x + k); q[k] = __builtin_amdgcn_readfirstlane((uint32_t)k + (threadIdx.x >> 6)); }
+    const uint32_t sx = __builtin_amdgcn_readfirstlane(__float_as_uint(xf) | 1u);
+    __syncthreads();
+    const uint64_t t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < kIters; ++it) {
+        asm volatile("v_fma_f32 %0, %16, %17, %0\ns_add_u32 %8, %8, %18\nv_fma_f32 %1, %16, %17, %1\ns_add_u32 %9, %9, %18\n"
+                     "v_fma_f32 %2, %16, %17, %2\ns_add_u32 %10, %10, %18\nv_fma_f32 %3, %16, %17, %3\ns_add_u32 %11, %11, %18\n"
+                     "v_fma_f32 %4, %16, %17, %4\ns_add_u32 %12, %12, %18\nv_fma_f32 %5, %16, %17, %5\ns_add_u32 %13, %13, %18\n"
+                     "v_fma_f32 %6, %16, %17, %6\ns_add_u32 %14, %14, %18\nv_fma_f32 %7, %16, %17, %7\ns_add_u32 %15, %15, %18"
+                     : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]),
+                       "+s"(q[0]), "+s"(q[1]), "+s"(q[2]), "+s"(q[3]), "+s"(q[4]), "+s"(q[5]), "+s"(q[6]), "+s"(q[7])
+                     : "v"(xf), "v"(yf), "s"(sx) : "scc");
+    }
+    asm volatile("s_nop 0" ::: "memory");
+    const uint64_t t1 = __builtin_amdgcn_s_memtime();
+    float acc = 0.0f;
+    for (int k = 0; k < 8; ++k) acc += r[k] + (float)q[k];
+    if ((threadIdx.x & 63) == 0) st[blockIdx.x * 4 + (threadIdx.x >> 6)] = Stamp{t0, t1};
+    if (acc == 12345.0f) out[0] = acc;
+}
+I64_KERNEL(v_lshladd64, A_LSHLADD64)
+I64_KERNEL(v_mad64, A_MAD64)
+I64_KERNEL(v_cmp64, A_CMP64)
+I64_KERNEL(v_shl64, A_SHL64)
+
 template <typename K, typename T>
 static void time_valu(const char* name, K kernel, T x, T y, int insts_per_slot, std::string& json) {
     int cus = 0;
@@ -259,6 +390,18 @@ static void run_valu() {
     time_valu("v_pk_fma_f32", v_pkfma, 1.0001f, 0.5f, 1, j);
     time_valu("v_pk_mul_f32", v_pkmul, 1.0001f, 0.5f, 1, j);
     time_valu("v_pk_add_f32", v_pkadd, 1.0001f, 0.5f, 1, j);
+    time_valu("s_add_u32", s_add, 3u, 5u, 1, j);
+    time_valu("s_mul_i32", s_mul, 3u, 5u, 1, j);
+    time_valu("s_mul_hi_u32", s_mulhi, 3u, 5u, 1, j);
+    time_valu("s_and_b64+s_add_u32", s_and64_add, 3u, 5u, 2, j);
+    time_valu("s_cmp+s_cselect", s_cmp_csel, 3u, 5u, 2, j);
+    time_valu("s_cmp+s_cbranch(not taken)+s_add", s_cmp_br_add, 3u, 0u, 3, j);
+    time_valu("s_cmp+s_cbranch(taken)", s_cmp_br_add, 3u, 0xFFFFFFFFu, 2, j);
+    time_valu("mix: v_fma_f32+s_add_u32 (per pair)", mix_valu_salu, 1.0001f, 0.5f, 1, j);
+    time_valu("v_lshl_add_u64", v_lshladd64, 3u, 5u, 1, j);
+    time_valu("v_mad_u64_u32", v_mad64, 3u, 5u, 1, j);
+    time_valu("v_cmp_lt_i64", v_cmp64, 3u, 5u, 1, j);
+    time_valu("v_lshlrev_b64", v_shl64, 3u, 5u, 1, j);
     int clk = 0;
     CK(hipDeviceGetAttribute(&clk, hipDeviceAttributeClockRate, 0));
     printf("{\"valu_issue_cost\": {%s}, \"unit\": \"cyc_*: s_memtime ticks, ns_*: HIP-event wall time (incl. ~10 us of launch), per wave64 instruction per SIMD\", \"clock_rate_khz\": %d}\n", j.c_str(), clk);
@@ -267,6 +410,7 @@ static void run_valu() {
 int main(int argc, char** argv) {
     if (argc > 1 && !strcmp(argv[1], "hbm")) run_hbm();
     else if (argc > 1 && !strcmp(argv[1], "valu")) run_valu();
-    else { fprintf(stderr, "usage: calib hbm|valu\n"); return 2; }
+    else if (argc > 1 && !strcmp(argv[1], "atomics")) run_atomic_shapes();
+    else { fprintf(stderr, "usage: calib hbm|valu|atomics\n"); return 2; }
     return 0;
 }
