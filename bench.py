@@ -367,6 +367,10 @@ def main():
 # logic 1.0-1.2; conversions, comparisons/selects, min/max/med3, floor/fract, shifts, 24/32-bit integer multiplies, 64-bit
 # adds 1.7-1.9; rcp/sqrt/rsq 3.4-3.5
 VALU_NS = {"full": 1.12, "half": 1.78, "trans": 3.45}
+# One SIMD starts at most one instruction of ANY kind (vector, scalar, LDS, memory) per ~1.05 ns: tools/calib.hip's mixed
+# streams (8 waves per SIMD) take 2.16 ns per v_fma_f32 + s_add_u32 pair and 2.08 ns per v_max_f32 + s_add_u32 pair, against
+# 1.13 / 1.73 / 1.76 ns for the three instructions alone -- scalar instructions are not free beside vector ones.
+ISSUE_SLOT_NS = 1.05
 
 
 def valu_roofline(pmc, kernel_ms):
@@ -382,10 +386,22 @@ def valu_roofline(pmc, kernel_ms):
     full = f32 + 0.5 * pmc["SQ_INSTS_VALU_INT32"] + 0.5 * other      # (other = moves/logic at full rate, compares/selects/min/max at half: split)
     half += 0.5 * other
     issue_ns = full * VALU_NS["full"] + half * VALU_NS["half"] + trans * VALU_NS["trans"]
-    return {"kernel_ms": round(kernel_ms, 4), "valu_insts_per_launch": round(total), "class_split": {"full_rate": round(full), "half_rate": round(half), "transcendental": round(trans)},
-            "issue_ns_per_wave_inst": VALU_NS, "valu_issue_ms": round(issue_ns / 1024 / 1e6, 4),
-            "frac": round(issue_ns / 1024 / 1e6 / kernel_ms, 4),
-            "what": "sum over instruction classes of (wave-instructions x issue cost) / (1024 SIMDs x kernel duration); costs from tools/calib.hip"}
+    out = {"kernel_ms": round(kernel_ms, 4), "valu_insts_per_launch": round(total), "class_split": {"full_rate": round(full), "half_rate": round(half), "transcendental": round(trans)},
+           "issue_ns_per_wave_inst": VALU_NS, "valu_issue_ms": round(issue_ns / 1024 / 1e6, 4),
+           "frac": round(issue_ns / 1024 / 1e6 / kernel_ms, 4),
+           "what": "sum over instruction classes of (wave-instructions x issue cost) / (1024 SIMDs x kernel duration); costs from tools/calib.hip"}
+    others = ("SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR")
+    if all(pmc.get(k) is not None for k in others):
+        # every instruction takes an issue slot of its SIMD; the vector ones also their execution time
+        n_all = total + sum(pmc[k] for k in others)
+        slots_ns = n_all * ISSUE_SLOT_NS
+        bound_ns = max(slots_ns, issue_ns)
+        out["issue"] = {"salu_insts_per_launch": round(pmc["SQ_INSTS_SALU"]), "lds_insts_per_launch": round(pmc["SQ_INSTS_LDS"]),
+                        "vmem_insts_per_launch": round(pmc["SQ_INSTS_VMEM_RD"] + pmc["SQ_INSTS_VMEM_WR"]), "slot_ns": ISSUE_SLOT_NS,
+                        "issue_slots_ms": round(slots_ns / 1024 / 1e6, 4), "bound_ms": round(bound_ns / 1024 / 1e6, 4),
+                        "frac": round(bound_ns / 1024 / 1e6 / kernel_ms, 4),
+                        "what": "max(all wave-instructions x one issue slot, vector execution time) / (1024 SIMDs x kernel duration): branches and waits not counted"}
+    return out
 
 
 def collect_pmc(args, kernel):
@@ -394,7 +410,8 @@ def collect_pmc(args, kernel):
     if shutil.which("rocprofv3") is None:
         return {"error": "rocprofv3 not on PATH"}
     groups = ["FETCH_SIZE", "WRITE_SIZE",
-              "SQ_INSTS_VALU SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32"]
+              "SQ_INSTS_VALU SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32",
+              "SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"]
     out = {}
     tmp = tempfile.mkdtemp(prefix="topo_pmc_")
     try:

@@ -289,30 +289,36 @@ SALU_KERNEL(s_mulhi, S_MULHI)
 SALU_KERNEL(s_and64_add, S_AND64)
 SALU_KERNEL(s_cmp_csel, S_CSEL)
 SALU_KERNEL(s_cmp_br_add, S_BR)
-// do vector and scalar instructions of different waves share the SIMD's issue?  8 v_fma_f32 + 8 s_add_u32 per iteration
-__global__ __launch_bounds__(256) void mix_valu_salu(Stamp* __restrict__ st, float xf, float yf, float* __restrict__ out) {
-    float r[8];
-    uint32_t q[8];
-    for (int k = 0; k < 8; ++k) { r[k] = xf + (float)(threadIdx.x + k); q[k] = __builtin_amdgcn_readfirstlane((uint32_t)k + (threadIdx.x >> 6)); }
-    const uint32_t sx = __builtin_amdgcn_readfirstlane(__float_as_uint(xf) | 1u);
-    __syncthreads();
-    const uint64_t t0 = __builtin_amdgcn_s_memtime();
-    for (int it = 0; it < kIters; ++it) {
-        asm volatile("v_fma_f32 %0, %16, %17, %0\ns_add_u32 %8, %8, %18\nv_fma_f32 %1, %16, %17, %1\ns_add_u32 %9, %9, %18\n"
-                     "v_fma_f32 %2, %16, %17, %2\ns_add_u32 %10, %10, %18\nv_fma_f32 %3, %16, %17, %3\ns_add_u32 %11, %11, %18\n"
-                     "v_fma_f32 %4, %16, %17, %4\ns_add_u32 %12, %12, %18\nv_fma_f32 %5, %16, %17, %5\ns_add_u32 %13, %13, %18\n"
-                     "v_fma_f32 %6, %16, %17, %6\ns_add_u32 %14, %14, %18\nv_fma_f32 %7, %16, %17, %7\ns_add_u32 %15, %15, %18"
-                     : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]),
-                       "+s"(q[0]), "+s"(q[1]), "+s"(q[2]), "+s"(q[3]), "+s"(q[4]), "+s"(q[5]), "+s"(q[6]), "+s"(q[7])
-                     : "v"(xf), "v"(yf), "s"(sx) : "scc");
+// do vector and scalar instructions share the SIMD's issue?  8 vector + 8 scalar instructions per iteration, interleaved
+#define MIX_KERNEL(NAME, VOP, SOP)                                                                                     \
+    __global__ __launch_bounds__(256) void NAME(Stamp* __restrict__ st, float xf, float yf, float* __restrict__ out) { \
+        float r[8];                                                                                                    \
+        uint32_t q[8];                                                                                                 \
+        for (int k = 0; k < 8; ++k) { r[k] = xf + (float)(threadIdx.x + k); q[k] = __builtin_amdgcn_readfirstlane((uint32_t)k + (threadIdx.x >> 6)); } \
+        const uint32_t sx = __builtin_amdgcn_readfirstlane(__float_as_uint(xf) | 1u);                                  \
+        __syncthreads();                                                                                               \
+        const uint64_t t0 = __builtin_amdgcn_s_memtime();                                                              \
+        for (int it = 0; it < kIters; ++it) {                                                                          \
+            asm volatile(VOP(0) "\n" SOP(8) "\n" VOP(1) "\n" SOP(9) "\n" VOP(2) "\n" SOP(10) "\n" VOP(3) "\n" SOP(11) "\n"    \
+                         VOP(4) "\n" SOP(12) "\n" VOP(5) "\n" SOP(13) "\n" VOP(6) "\n" SOP(14) "\n" VOP(7) "\n" SOP(15)        \
+                         : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]),  \
+                           "+s"(q[0]), "+s"(q[1]), "+s"(q[2]), "+s"(q[3]), "+s"(q[4]), "+s"(q[5]), "+s"(q[6]), "+s"(q[7])   \
+                         : "v"(xf), "v"(yf), "s"(sx) : "scc");                                                         \
+        }                                                                                                              \
+        asm volatile("s_nop 0" ::: "memory");                                                                          \
+        const uint64_t t1 = __builtin_amdgcn_s_memtime();                                                              \
+        float acc = 0.0f;                                                                                              \
+        for (int k = 0; k < 8; ++k) acc += r[k] + (float)q[k];                                                         \
+        if ((threadIdx.x & 63) == 0) st[blockIdx.x * 4 + (threadIdx.x >> 6)] = Stamp{t0, t1};                          \
+        if (acc == 12345.0f) out[0] = acc;                                                                             \
     }
-    asm volatile("s_nop 0" ::: "memory");
-    const uint64_t t1 = __builtin_amdgcn_s_memtime();
-    float acc = 0.0f;
-    for (int k = 0; k < 8; ++k) acc += r[k] + (float)q[k];
-    if ((threadIdx.x & 63) == 0) st[blockIdx.x * 4 + (threadIdx.x >> 6)] = Stamp{t0, t1};
-    if (acc == 12345.0f) out[0] = acc;
-}
+#define MV_FMA(k) "v_fma_f32 %" #k ", %16, %17, %" #k
+#define MV_MAX(k) "v_max_f32 %" #k ", %16, %" #k
+#define MS_ADD(k) "s_add_u32 %" #k ", %" #k ", %18"
+#define MS_MUL(k) "s_mul_i32 %" #k ", %" #k ", %18"
+MIX_KERNEL(mix_valu_salu, MV_FMA, MS_ADD)
+MIX_KERNEL(mix_half_salu, MV_MAX, MS_ADD)
+MIX_KERNEL(mix_fma_smul, MV_FMA, MS_MUL)
 I64_KERNEL(v_lshladd64, A_LSHLADD64)
 I64_KERNEL(v_mad64, A_MAD64)
 I64_KERNEL(v_cmp64, A_CMP64)
@@ -398,6 +404,8 @@ static void run_valu() {
     time_valu("s_cmp+s_cbranch(not taken)+s_add", s_cmp_br_add, 3u, 0u, 3, j);
     time_valu("s_cmp+s_cbranch(taken)", s_cmp_br_add, 3u, 0xFFFFFFFFu, 2, j);
     time_valu("mix: v_fma_f32+s_add_u32 (per pair)", mix_valu_salu, 1.0001f, 0.5f, 1, j);
+    time_valu("mix: v_max_f32+s_add_u32 (per pair)", mix_half_salu, 1.0001f, 0.5f, 1, j);
+    time_valu("mix: v_fma_f32+s_mul_i32 (per pair)", mix_fma_smul, 1.0001f, 0.5f, 1, j);
     time_valu("v_lshl_add_u64", v_lshladd64, 3u, 5u, 1, j);
     time_valu("v_mad_u64_u32", v_mad64, 3u, 5u, 1, j);
     time_valu("v_cmp_lt_i64", v_cmp64, 3u, 5u, 1, j);
