@@ -884,18 +884,19 @@ __global__ __launch_bounds__(256) void k_raster_big(FrameParams P) {
 }
 
 // ---- resolve: fs_main for the winner of every pixel, then the post pass --------------------------------
-// A 64 x 16 px block is shaded by one workgroup, wave w taking rows w, w + 4, w + 8, w + 12 (interleaved: the terrain/sky
-// boundary is mostly horizontal, so the four waves of a block get similar work).
+// A workgroup takes 64 x 16 px blocks; wave w shades rows 4w .. 4w+3 of each (a 64 x 4 px strip) on its own: its own halo,
+// depth tile and record table, no barrier once the tables are staged (see k_resolve).
 //
-// The grid is PERSISTENT (as many workgroups as are resident at once) and each workgroup walks the blocks with a static
-// stride, software-pipelined: a block's shading needs two dependent trips to memory before it can start -- the segment
-// marks that say whether anything was drawn there (about half of a panorama is sky: such a block is written out as
-// constants without reading a key; with every tap at depth 1 the contour term is exactly 0 and the post pass returns the
-// cleared texel unchanged), then the visibility keys -- and at ~1.5 us per trip under load those two waits were three
-// quarters of a block's 12 us in a one-block-per-workgroup kernel (measured: with ALL arithmetic removed it still took
-// 0.38 of its 0.50 ms).  So while block i is shaded, the keys of block i+1 are already on their way into registers (each
-// lane reads the keys of its own four pixels, 512-byte row segments; the 1 px halo ring by the first 164 threads) and so
-// are the marks of block i+2; the sRGB tables are staged into LDS once per workgroup instead of once per block.
+// The grid is PERSISTENT (four times the resident workgroups) and each workgroup walks its blocks with a static stride,
+// software-pipelined: a strip's shading needs two dependent trips to memory before it can start -- the segment marks that
+// say whether anything was drawn there (about half of a panorama is sky: such a strip is written out as constants without
+// reading a key; with every tap at depth 1 the contour term is exactly 0 and the post pass returns the cleared texel
+// unchanged), then the visibility keys -- and at ~1.5 us per trip under load those two waits were three quarters of a
+// block's 12 us in a one-block-per-workgroup kernel (measured: with ALL arithmetic removed it still took 0.38 of its
+// 0.50 ms).  So the marks of up to 64 strips are read in one go (lane j: strip j), and while strip i is shaded the keys of
+// strip i+1 are already on their way into registers (each lane reads the keys of its own four pixels, 512-byte row
+// segments, and three depth words of the 140-entry ring around the strip); the sRGB tables are staged into LDS once per
+// workgroup.
 //
 // Winners are shared: the near field consists of triangles tens to thousands of pixels large, and two thirds of a
 // pixel's arithmetic (three vs_main, the perspective divides, the doubled area: resolve_setup) depends on the winning
