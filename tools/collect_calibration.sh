@@ -8,6 +8,7 @@ R=$(pwd)
 O=$R/gpurun_out/calib
 mkdir -p $O
 $R/tools/_build/calib valu > $O/valu.json
+$R/tools/_build/calib atomics > $O/atomics.json
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/$c -o cal -- $R/tools/_build/calib hbm > $O/hbm_$c.log 2>&1

@@ -28,4 +28,6 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         e[c + "_counted"] = round(med)
         if relevant and med > 0:
             e[c + "_factor_known_over_counted"] = round(known[name] / med, 4)
+if os.path.exists(os.path.join(root, "atomics.json")):      # 64-bit atomic min: rate against the shape of the 512 bytes a wave touches
+    out["atomics"] = json.load(open(os.path.join(root, "atomics.json")))
 print(json.dumps(out, indent=1))
