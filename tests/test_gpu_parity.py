@@ -695,6 +695,23 @@ def test_random_frames(topo, orc):
         assert (g.counters()["status"] & 1) == 0
 
 
+def test_strip_edges_of_the_resolve_pass(topo, orc):
+    """k_resolve works in 64 x 4 px strips of 64 x 16 px blocks, each wave with its own 1 px halo ring: targets one to a few
+    pixels high, heights around the strip and block sizes, widths just under / at / over one and two strip widths -- the
+    clamped halo, the partial last strip and the lanes beyond the right edge all decide pixels here (contours included)."""
+    sc = Scene(40, 1, 1, eye_dh=30.0)
+    g, o = both(topo, orc, 16, 16)
+    sc.load(g)
+    sc.load(o)
+    sizes = [(1, 1), (2, 1), (5, 3), (63, 4), (64, 4), (65, 5), (64, 15), (127, 16), (128, 17), (129, 7), (191, 33), (3, 70)]
+    for k, (W, H) in enumerate(sizes):
+        for mode in (0, 2):
+            u, pu = sc.uniforms(W, H, 40.0 * k, -12.0 + 3.0 * k, 70.0, mode), topo.post_uniforms(W, H)
+            g.update(W, H, u, pu)
+            o.update(W, H, u, pu)
+            assert_same_frame(g.render(), o.render(), f"strip edges: {W}x{H} mode {mode}")
+
+
 def test_timing_slots_select_events(topo, orc):
     """topo_set_timing_slots: unselected per-kernel slots read 0, the total is always measured, frames are unchanged."""
     sc = Scene(64, 1, 1, eye_dh=60)
