@@ -341,12 +341,16 @@ def test_normal_texel_fast_path():
     L.emul_normal_fast_check.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     rng = np.random.default_rng(21)
     total_fast = 0
-    for rep in range(6):
+    for rep in range(7):
         n = 4_000_000
         xs = rng.uniform(20.0, 120.0, n).astype(np.float32)          # half-steps in metres (COP90: ~46 x 33 m at 45 degrees)
         ys = rng.uniform(5.0, 120.0, n).astype(np.float32)
-        scale = np.float32([0.5, 30.0, 300.0, 3000.0, 3.0e5, 1.0e-3][rep])
+        scale = np.float32([0.5, 30.0, 300.0, 3000.0, 3.0e5, 1.0e-3, 1.0][rep])
         h = (rng.standard_normal((n, 4)) * scale + rng.uniform(0, 4000, (n, 1))).astype(np.float32)
+        if rep == 6:      # degenerate scales: the squared length underflows (the fast route must hand over below 1e-30)
+            xs = (10.0 ** rng.uniform(-14.0, -2.0, n)).astype(np.float32)
+            ys = (10.0 ** rng.uniform(-14.0, -2.0, n)).astype(np.float32)
+            h = (rng.standard_normal((n, 4)) * (10.0 ** rng.uniform(-16.0, -3.0, (n, 1)))).astype(np.float32)
         if rep == 1:      # adversarial: choose hR so that component x lands (in f64) right on a code boundary
             k = rng.integers(1, 255, n)
             nxt = (k - 127.5) / 127.5                                  # n_x with 127.5 n + 128 = k + 0.5... a boundary of floor(t)

@@ -302,9 +302,13 @@ TOPO_HD bool normal_texel_fast(float x, float y, float hT, float hL, float hR, f
     const float tx = fmaf(vx * r, 127.5f, 128.0f), ty = fmaf(vy * r, 127.5f, 128.0f), tz = fmaf(vz * r, 127.5f, 128.0f);
     const float fx = floorf(tx), fy = floorf(ty), fz = floorf(tz);
     const float gx = tx - fx, gy = ty - fy, gz = tz - fz;      // exact: t in [0, 256)
-    // every comparison is false for a NaN, so a non-finite intermediate fails the test
-    const bool ok = gx >= kNormalGuard && gx <= 1.0f - kNormalGuard && gy >= kNormalGuard && gy <= 1.0f - kNormalGuard &&
-                    gz >= kNormalGuard && gz <= 1.0f - kNormalGuard && tx < 256.0f && ty < 256.0f && tz < 256.0f && tx >= 0.0f && ty >= 0.0f && tz >= 0.0f;
+    // |g - 1/2| <= 1/2 - guard  <=>  guard <= g <= 1 - guard up to the rounding of g - 1/2 (6e-8: the guard band has 1.2e-4 to
+    // spare).  ss >= 1e-30 keeps the squares' underflow out of the error bound (a term that underflows is < 1e-8 of such an
+    // ss); with it |v_i r| <= 1 + 1e-6, so t lies in [0.49, 255.51] and needs no range test: an overflowed ss gives r = 0,
+    // t = 128, g = 0; a NaN anywhere fails every comparison.  (Seven instructions instead of twenty-three: the kernel is as
+    // much bound by instruction issue as by HBM.)
+    constexpr float kLim = 0.5f - kNormalGuard;
+    const bool ok = ss >= 1.0e-30f && fabsf(gx - 0.5f) <= kLim && fabsf(gy - 0.5f) <= kLim && fabsf(gz - 0.5f) <= kLim;
     texel = (uint32_t)fx | ((uint32_t)fy << 8) | ((uint32_t)fz << 16);      // alpha: to_unorm8(0) = 0
     return ok;
 }
