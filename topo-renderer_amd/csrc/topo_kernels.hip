@@ -217,16 +217,21 @@ __global__ __launch_bounds__(256) void k_normals_interior(const TileDev* __restr
     __syncthreads();
     const int gx = x0 + tx;
     const float xs = deg2rad(t.scale_x) * kR0;
+    const bool col_in = gx >= 1 && gx < W - 1;
+    // (a running output pointer and the column tests outside the loop: this kernel is as much bound by the number of
+    // instructions it issues as by HBM, and the compiler otherwise rebuilds the 64-bit address in every row)
+    auto out = normals + ((size_t)(y0 + wy) * W + (gx < W ? gx : 0));
+    const size_t out_step = (size_t)4 * W;
 #pragma unroll
-    for (int r = wy; r < ROWS; r += 4) {
+    for (int r = wy; r < ROWS; r += 4, out += out_step) {
         const int gy = y0 + r;
         if (gy >= H) break;      // (wave-uniform)
-        const bool interior = gx >= 1 && gy >= 1 && gx < W - 1 && gy < H - 1;
+        const bool interior = col_in && gy >= 1 && gy < H - 1;
         const float hT = tile[r][tx + 1], hL = tile[r + 1][tx], hR = tile[r + 1][tx + 2], hB = tile[r + 2][tx + 1], ys = s_ys[r];
         uint32_t texel = 0;
         const bool settled = normal_texel_fast(xs, ys, hT, hL, hR, hB, texel) || !interior;
         if (!settled) texel = normal_texel(xs, ys, hT, hL, hR, hB);      // the guard band and non-finite heights: the full chain
-        if (gx < W) normals[(size_t)gy * W + gx] = interior ? texel : 0u;
+        if (gx < W) *out = interior ? texel : 0u;
     }
 }
 
