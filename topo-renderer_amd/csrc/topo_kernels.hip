@@ -167,46 +167,59 @@ __global__ __launch_bounds__(64) void k_block_minmax(TileDev t, uint32_t w, uint
     }
 }
 
-// Interior normals (compute_normals_shader.wgsl:22-51) of a batch of tiles (blockIdx.z).  64 x ROWS output texels per
-// 256-thread workgroup; the (ROWS+2) x 66 height tile is staged in LDS row by row -- wave w takes rows w, w + 4, ...: one
-// coalesced 256-byte read per row plus a two-lane read for the right halo -- each texel's four taps then come from LDS;
-// cos(latitude) is evaluated once per row.  The border ring, which the shader leaves untouched (:30-33) and which is
-// zero in a freshly created texture, is written as zero here so no separate clear is needed; seam/corner passes run
-// afterwards.  ROWS is the LDS tile-size knob (topo_set_normals_lds_rows).
+// Interior normals (compute_normals_shader.wgsl:22-51) of a batch of tiles (blockIdx.z).  128 x ROWS output texels per
+// 256-thread workgroup, TWO horizontally adjacent texels per lane: the kernel issues as many instructions as it moves
+// bytes (one texel per lane: ~90 instructions per 64 texels, 0.21 ms of issue slots beside 0.20 ms of HBM time at c4), and
+// everything that is not the stencil's own arithmetic -- addresses, edge tests, LDS traffic, loop control, the staging
+// loads -- is paid per lane, not per texel.  The (ROWS+2) x 130 height tile is staged in LDS row by row -- wave w takes
+// rows w, w + 4, ...: one coalesced 512-byte read per row (a pair of columns per lane) plus a two-lane read for the halo
+// columns -- each texel's four taps then come from LDS; cos(latitude) is evaluated once per row.  The border ring, which
+// the shader leaves untouched (:30-33) and which is zero in a freshly created texture, is written as zero here so no
+// separate clear is needed; seam/corner passes run afterwards.  ROWS is the LDS tile-size knob
+// (topo_set_normals_lds_rows).
 // Arithmetic: normal_texel_fast() -- a reciprocal-square-root estimate and a guard band around the 8-bit code boundaries
 // -- settles 998 texels in 1000; a wave in which some lane's texel falls inside the guard band (or is not finite)
 // evaluates the full chain (correctly rounded sqrt, three IEEE divisions) for those lanes.  Same bytes either way.
+typedef float f32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));         // a pair of floats at any 4-byte boundary
+typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
 template <int ROWS>
 __global__ __launch_bounds__(256) void k_normals_interior(const TileDev* __restrict__ tiles, uint32_t first, int W, int H) {
-    __shared__ float tile[ROWS + 2][68];      // 66 used; the row pitch keeps rows 16-byte aligned
+    // column c of the tile (c = -1 .. 128) lives at index c + 2: a lane's pair (2 tx, 2 tx + 1) at the even index 2 tx + 2
+    __shared__ __attribute__((aligned(16))) float tile[ROWS + 2][132];
     __shared__ float s_ys[ROWS];
     const TileDev& t = tiles[first + blockIdx.z];
     const auto heights = TOPO_GLOBAL_F32(t.heights);          // global, not flat, memory operations
     const auto normals = TOPO_GLOBAL_U32_RW(t.normals);
-    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * ROWS;
+    const int x0 = blockIdx.x * 128, y0 = blockIdx.y * ROWS;
     const int tx = threadIdx.x & 63, wy = threadIdx.x >> 6;
+    const int gx0 = x0 + 2 * tx;                              // the lane's first column (the second: gx0 + 1)
     {
-        // columns -1..62 by all lanes, 63 and 64 by lanes 0 and 1.  Every load is unconditional (clamped address, value
-        // discarded where it does not apply) and all of a wave's loads are issued before the first LDS write: a branch
-        // around a load makes the compiler wait for it before going on, one trip to memory per row.
+        // Every load is unconditional (clamped address, value discarded where it does not apply) and all of a wave's loads
+        // are issued before the first LDS write: a branch around a load makes the compiler wait for it before going on, one
+        // trip to memory per row.  The pair is read from columns (px, px + 1) with px clamped to W - 2, so that both exist.
         constexpr int kIter = (ROWS + 2 + 3) / 4;
-        const int gx = x0 + tx - 1, gx2 = x0 + 63 + (tx & 1);
-        const int cx = gx < 0 ? 0 : (gx > W - 1 ? W - 1 : gx), cx2 = gx2 > W - 1 ? W - 1 : gx2;
-        float a[kIter], b[kIter];
+        const int px = gx0 > W - 2 ? W - 2 : gx0;
+        const int hx = x0 - 1 + 129 * (tx & 1);               // lanes 0 / 1: columns -1 / 128
+        const int chx = hx < 0 ? 0 : (hx > W - 1 ? W - 1 : hx);
+        f32x2_a4 a[kIter];
+        float b[kIter];
 #pragma unroll
         for (int k = 0; k < kIter; ++k) {
             const int gy = y0 + wy + 4 * k - 1;
             const int cy = gy < 0 ? 0 : (gy > H - 1 ? H - 1 : gy);
-            a[k] = heights[(size_t)cy * W + cx];
-            b[k] = heights[(size_t)cy * W + cx2];
+            a[k] = *(const __attribute__((address_space(1))) f32x2_a4*)(heights + ((size_t)cy * W + px));
+            b[k] = heights[(size_t)cy * W + chx];
         }
 #pragma unroll
         for (int k = 0; k < kIter; ++k) {
             const int ly = wy + 4 * k, gy = y0 + ly - 1;
             const bool row_in = gy >= 0 && gy < H;
             if (ly < ROWS + 2) {
-                tile[ly][tx] = row_in && gx >= 0 && gx < W ? a[k] : 0.0f;
-                if (tx < 2) tile[ly][64 + tx] = row_in && gx2 < W ? b[k] : 0.0f;
+                // (gx0 == W - 1: the tile's last column is the second element of the clamped pair)
+                const float v0 = !row_in || gx0 > W - 1 ? 0.0f : (gx0 == W - 1 ? a[k].y : a[k].x);
+                const float v1 = row_in && gx0 + 1 <= W - 1 ? a[k].y : 0.0f;
+                *reinterpret_cast<float2*>(&tile[ly][2 * tx + 2]) = make_float2(v0, v1);
+                if (tx < 2) tile[ly][1 + 129 * tx] = row_in && hx >= 0 && hx < W ? b[k] : 0.0f;
             }
         }
     }
@@ -215,23 +228,33 @@ __global__ __launch_bounds__(256) void k_normals_interior(const TileDev* __restr
         s_ys[threadIdx.x] = deg2rad(t.scale_y) * kR0 * cos_f(deg2rad(latitude));
     }
     __syncthreads();
-    const int gx = x0 + tx;
     const float xs = deg2rad(t.scale_x) * kR0;
-    const bool col_in = gx >= 1 && gx < W - 1;
-    // (a running output pointer and the column tests outside the loop: this kernel is as much bound by the number of
-    // instructions it issues as by HBM, and the compiler otherwise rebuilds the 64-bit address in every row)
-    auto out = normals + ((size_t)(y0 + wy) * W + (gx < W ? gx : 0));
+    const bool col_in0 = gx0 >= 1 && gx0 < W - 1, col_in1 = gx0 + 1 < W - 1;      // (gx0 + 1 >= 1 always)
+    auto out = normals + ((size_t)(y0 + wy) * W + (gx0 < W ? gx0 : 0));
     const size_t out_step = (size_t)4 * W;
 #pragma unroll
     for (int r = wy; r < ROWS; r += 4, out += out_step) {
         const int gy = y0 + r;
         if (gy >= H) break;      // (wave-uniform)
-        const bool interior = col_in && gy >= 1 && gy < H - 1;
-        const float hT = tile[r][tx + 1], hL = tile[r + 1][tx], hR = tile[r + 1][tx + 2], hB = tile[r + 2][tx + 1], ys = s_ys[r];
-        uint32_t texel = 0;
-        const bool settled = normal_texel_fast(xs, ys, hT, hL, hR, hB, texel) || !interior;
-        if (!settled) texel = normal_texel(xs, ys, hT, hL, hR, hB);      // the guard band and non-finite heights: the full chain
-        if (gx < W) *out = interior ? texel : 0u;
+        const bool row_in = gy >= 1 && gy < H - 1;
+        const float2 top = *reinterpret_cast<const float2*>(&tile[r][2 * tx + 2]), bot = *reinterpret_cast<const float2*>(&tile[r + 2][2 * tx + 2]);
+        const float2 mid = *reinterpret_cast<const float2*>(&tile[r + 1][2 * tx + 2]);      // the pair's own heights: each is the other's neighbour
+        const float hl = tile[r + 1][2 * tx + 1], hr = tile[r + 1][2 * tx + 4], ys = s_ys[r];
+        uint32_t t0 = 0, t1 = 0;
+        const bool in0 = col_in0 && row_in, in1 = col_in1 && row_in;
+        const bool settled0 = normal_texel_fast(xs, ys, top.x, hl, mid.y, bot.x, t0) || !in0;
+        const bool settled1 = normal_texel_fast(xs, ys, top.y, mid.x, hr, bot.y, t1) || !in1;
+        if (!settled0) t0 = normal_texel(xs, ys, top.x, hl, mid.y, bot.x);      // the guard band and non-finite heights: the full chain
+        if (!settled1) t1 = normal_texel(xs, ys, top.y, mid.x, hr, bot.y);
+        t0 = in0 ? t0 : 0u;
+        t1 = in1 ? t1 : 0u;
+        if (gx0 + 1 < W) {
+            u32x2_a4 v;
+            v.x = t0; v.y = t1;
+            *(__attribute__((address_space(1))) u32x2_a4*)(out) = v;
+        } else if (gx0 < W) {
+            *out = t0;
+        }
     }
 }
 
@@ -1442,7 +1465,7 @@ void launch_normals_interior(const TileDev* tiles, uint32_t first, uint32_t coun
     if (count == 0) return;
     const dim3 block(256);
 #define TOPO_K1(R)                                                                                                     \
-    hipLaunchKernelGGL(k_normals_interior<R>, dim3((w + 63) / 64, (h + (R)-1) / (R), count), block, 0, s, tiles, first, \
+    hipLaunchKernelGGL(k_normals_interior<R>, dim3((w + 127) / 128, (h + (R)-1) / (R), count), block, 0, s, tiles, first, \
                        (int)w, (int)h)
     switch (lds_rows) {
         case 4: TOPO_K1(4); break;
