@@ -251,7 +251,8 @@ __global__ __launch_bounds__(256) void k_normals_interior(const TileDev* __restr
         if (gx0 + 1 < W) {
             u32x2_a4 v;
             v.x = t0; v.y = t1;
-            *(__attribute__((address_space(1))) u32x2_a4*)(out) = v;
+            // (non-temporal: the texture is written once here and read much later -- 0.246 -> 0.235 ms at c4)
+            __builtin_nontemporal_store(v, (__attribute__((address_space(1))) u32x2_a4*)(out));
         } else if (gx0 < W) {
             *out = t0;
         }
