@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """LDS tile-size sweep of the interior-normals kernel (BASELINE config 3: 5x5 degree mosaic, 25 tiles).
 
-For each ROWS in {4, 8, 16, 32, 64} (output rows per 256-thread workgroup; the LDS tile is (ROWS+2) x 66 floats)
+For each ROWS in {4, 8, 16, 32, 64} (output rows per 256-thread workgroup of 128 columns; the LDS tile is (ROWS+2) x 132 floats)
 re-runs the load phase over the resident heights and prints the HIP-event time and the achieved GB/s against
 the 8 B/texel algorithmic traffic (4 B height read + 4 B normal write).  Run it under
 `rocprofv3 --kernel-trace --stats` to get the per-instantiation kernel durations.
@@ -27,6 +27,6 @@ for rows in (4, 8, 16, 32, 64):
         r.recompute_normals()
         ms.append(r.timings()["load"])
     best = min(ms[2:])
-    out.append({"lds_rows": rows, "lds_bytes": (rows + 2) * 66 * 4 + rows * 4, "load_ms": round(best, 4),
+    out.append({"lds_rows": rows, "lds_bytes": (rows + 2) * 132 * 4 + rows * 4, "load_ms": round(best, 4),
                 "GBps": round(bytes_ / (best / 1e3) / 1e9, 1), "frac_of_8TBps": round(bytes_ / (best / 1e3) / 8e12, 4)})
 print(json.dumps({"workload": f"{deg}x{deg} deg mosaic, {deg*deg} tiles of 1200x1200", "algorithmic_bytes": bytes_, "sweep": out}))
