@@ -162,8 +162,8 @@ int TerrainRenderer::upload_seam_jobs(const std::vector<EdgeJob>& edges, const s
     return TOPO_OK;
 }
 void TerrainRenderer::launch_seam_jobs(size_t n_edges, size_t n_corners) {
-    launch_normals_edges((const TileDev*)d_tiles_, (const EdgeJob*)d_edge_jobs_, (uint32_t)n_edges, tile_w_, tile_h_, stream_);
-    launch_normals_corners((const TileDev*)d_tiles_, (const CornerJob*)d_corner_jobs_, (uint32_t)n_corners, tile_w_, tile_h_, stream_);
+    launch_normals_border((const TileDev*)d_tiles_, (const EdgeJob*)d_edge_jobs_, (uint32_t)n_edges, (const CornerJob*)d_corner_jobs_, (uint32_t)n_corners,
+                          tile_w_, tile_h_, stream_);
 }
 int TerrainRenderer::run_seam_jobs(const std::vector<EdgeJob>& edges, const std::vector<CornerJob>& corners) {
     if (int rc = upload_seam_jobs(edges, corners)) return rc;

@@ -97,8 +97,8 @@ void launch_block_minmax(const TileDev& tile, uint32_t w, uint32_t h, hipStream_
 // interior normals of tiles[first .. first+count); also zeroes their border ring (fresh Rgba8Unorm texture)
 void launch_normals_interior(const TileDev* tiles, uint32_t first, uint32_t count, uint32_t w, uint32_t h, int lds_rows,
                              hipStream_t s);
-void launch_normals_edges(const TileDev* tiles, const EdgeJob* jobs, uint32_t n_jobs, uint32_t w, uint32_t h, hipStream_t s);
-void launch_normals_corners(const TileDev* tiles, const CornerJob* jobs, uint32_t n_jobs, uint32_t w, uint32_t h, hipStream_t s);
+void launch_normals_border(const TileDev* tiles, const EdgeJob* edges, uint32_t n_edges, const CornerJob* corners, uint32_t n_corners, uint32_t w,
+                           uint32_t h, hipStream_t s);      // the seam and corner passes of any number of jobs, one launch
 
 // frame phase (render)
 void launch_clear(const FrameParams& p, hipStream_t s);   // re-initialises the marked segments and the queue counters

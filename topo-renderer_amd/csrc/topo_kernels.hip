@@ -1,7 +1,7 @@
 // topo_kernels.hip -- gfx950 (CDNA4, wave64) kernels of the terrain path.
 //
 //   load phase   k_tiff_rows (GeoTIFF predictor / layout), k_block_minmax (+ per-tile sin/cos tables and cull bounds),
-//                k_normals_interior<ROWS>, k_normals_edge, k_normals_corner (compute_normals*.wgsl; once per add_terrain)
+//                k_normals_interior<ROWS>, k_normals_border (seams + corners) (compute_normals*.wgsl; once per add_terrain)
 //   frame phase  k_clear -> k_cull -> [near] k_raster -> k_raster_rare -> k_raster_big -> k_occlusion ->
 //                [far survivors] k_raster -> k_raster_rare -> k_raster_big -> k_resolve
 //                (render_shader.wgsl vs_main + fixed-function raster/depth, fs_main, postprocessing_shader.wgsl)
@@ -259,16 +259,17 @@ __global__ __launch_bounds__(256) void k_normals_interior(const TileDev* __restr
     }
 }
 
-// Seam normals (compute_normals_edge_shader.wgsl:25-105), one job per blockIdx.y.
-__global__ __launch_bounds__(64) void k_normals_edge(const TileDev* __restrict__ tiles, const EdgeJob* __restrict__ jobs, int W, int H) {
-    const EdgeJob job = jobs[blockIdx.y];
+// Seam normals (compute_normals_edge_shader.wgsl:25-105): 64 texels (piece `block_x`) of seam job `job_index`.
+__device__ __forceinline__ void normals_edge_body(const TileDev* __restrict__ tiles, const EdgeJob* __restrict__ jobs, int W, int H, uint32_t block_x,
+                                                  uint32_t job_index) {
+    const EdgeJob job = jobs[job_index];
     const TileDev &lt = tiles[job.lt], &rb = tiles[job.rb], &u = tiles[job.uni];
     const auto h_lt = TOPO_GLOBAL_F32(lt.heights);
     const auto h_rb = TOPO_GLOBAL_F32(rb.heights);
     const auto n_lt = TOPO_GLOBAL_U32_RW(lt.normals);
     const auto n_rb = TOPO_GLOBAL_U32_RW(rb.normals);
     const float raster_y = u.raster_y, model_y = u.model_y, scale_x = u.scale_x, scale_y = u.scale_y;
-    const int id = blockIdx.x * 64 + threadIdx.x;
+    const int id = (int)block_x * 64 + (int)threadIdx.x;
     if (id < 1 || id >= W - 1) return;
     const float xs = deg2rad(fabsf(scale_x)) * kR0;
     const float ys0 = deg2rad(fabsf(scale_y)) * kR0;
@@ -296,9 +297,9 @@ __global__ __launch_bounds__(64) void k_normals_edge(const TileDev* __restrict__
 
 // Shared corner of a 2x2 block (compute_normals_corner_shader.wgsl:29-63), one job per lane; `top` comes from
 // the bottom-right tile at (0, H-2) exactly as the shader reads it (:49).
-__global__ __launch_bounds__(64) void k_normals_corner(const TileDev* __restrict__ tiles, const CornerJob* __restrict__ jobs,
-                                                       uint32_t n_jobs, int W, int H) {
-    const uint32_t j = blockIdx.x * 64 + threadIdx.x;
+__device__ __forceinline__ void normals_corner_body(const TileDev* __restrict__ tiles, const CornerJob* __restrict__ jobs, uint32_t n_jobs, int W, int H,
+                                                    uint32_t block) {
+    const uint32_t j = block * 64 + threadIdx.x;
     if (j >= n_jobs) return;
     const CornerJob job = jobs[j];
     const TileDev &lt = tiles[job.lt], &rt = tiles[job.rt], &lb = tiles[job.lb], &rb = tiles[job.rb], &u = tiles[job.uni];
@@ -314,6 +315,15 @@ __global__ __launch_bounds__(64) void k_normals_corner(const TileDev* __restrict
     TOPO_GLOBAL_U32_RW(rt.normals)[(size_t)(H - 1) * W + 0] = texel;
     TOPO_GLOBAL_U32_RW(lb.normals)[(size_t)0 * W + (W - 1)] = texel;
     TOPO_GLOBAL_U32_RW(rb.normals)[0] = texel;
+}
+
+// Both border passes in one launch (they write disjoint texels): workgroups [0, chunks * n_edges) take the seam jobs (chunks =
+// 64-texel pieces of a seam), the rest the corner jobs, 64 per workgroup.
+__global__ __launch_bounds__(64) void k_normals_border(const TileDev* __restrict__ tiles, const EdgeJob* __restrict__ edges, uint32_t n_edges,
+                                                       uint32_t chunks, const CornerJob* __restrict__ corners, uint32_t n_corners, int W, int H) {
+    const uint32_t n_edge_blocks = chunks * n_edges;
+    if (blockIdx.x < n_edge_blocks) normals_edge_body(tiles, edges, W, H, blockIdx.x % chunks, blockIdx.x / chunks);
+    else normals_corner_body(tiles, corners, n_corners, W, H, blockIdx.x - n_edge_blocks);
 }
 
 // ======================================================================================================
@@ -1478,14 +1488,11 @@ void launch_normals_interior(const TileDev* tiles, uint32_t first, uint32_t coun
 #undef TOPO_K1
 }
 
-void launch_normals_edges(const TileDev* tiles, const EdgeJob* jobs, uint32_t n_jobs, uint32_t w, uint32_t h, hipStream_t s) {
-    if (n_jobs == 0) return;
-    hipLaunchKernelGGL(k_normals_edge, dim3((w + 63) / 64, n_jobs), dim3(64), 0, s, tiles, jobs, (int)w, (int)h);
-}
-
-void launch_normals_corners(const TileDev* tiles, const CornerJob* jobs, uint32_t n_jobs, uint32_t w, uint32_t h, hipStream_t s) {
-    if (n_jobs == 0) return;
-    hipLaunchKernelGGL(k_normals_corner, dim3((n_jobs + 63) / 64), dim3(64), 0, s, tiles, jobs, n_jobs, (int)w, (int)h);
+void launch_normals_border(const TileDev* tiles, const EdgeJob* edges, uint32_t n_edges, const CornerJob* corners, uint32_t n_corners, uint32_t w,
+                           uint32_t h, hipStream_t s) {
+    const uint32_t chunks = (w + 63) / 64, blocks = chunks * n_edges + (n_corners + 63) / 64;
+    if (blocks == 0) return;
+    hipLaunchKernelGGL(k_normals_border, dim3(blocks), dim3(64), 0, s, tiles, edges, n_edges, chunks, corners, n_corners, (int)w, (int)h);
 }
 
 void launch_clear(const FrameParams& p, hipStream_t s) {
