@@ -506,6 +506,10 @@ __global__ __launch_bounds__(256) void k_cull(FrameParams P) {
 // One wave per far candidate: the block is dropped iff EVERY pixel of its footprint already holds a depth below
 // the block's lower bound -- then none of its fragments could pass `Less`.  Pixels in the gaps between tiles, or
 // anywhere nothing nearer has been drawn, keep the block alive, so the filter is exact by construction.
+#ifndef TOPO_OCC_ROWS
+#define TOPO_OCC_ROWS 4
+#endif
+constexpr uint32_t kOccRows = TOPO_OCC_ROWS;      // rows of a footprint whose depths are in flight before the wave votes
 __global__ __launch_bounds__(256) void k_occlusion(FrameParams P) {
     // between the two raster phases: the rare/big queues keep growing, the second phase starts where the first ended
     // (nothing enqueues while this kernel runs, and the consumers of the marks are launched after it)
@@ -517,22 +521,26 @@ __global__ __launch_bounds__(256) void k_occlusion(FrameParams P) {
     if (count > P.work_cap) count = P.work_cap;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave_global = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wave_count = gridDim.x * 4;
+    FarItem fi_next = P.far[wave_global < count ? wave_global : 0u];      // (the next candidate's record is fetched under the current one's scan)
     for (uint32_t item = wave_global; item < count; item += wave_count) {
-        const FarItem fi = P.far[item];
+        const FarItem fi = fi_next;
+        fi_next = P.far[item + wave_count < count ? item + wave_count : item];
         const uint64_t* vis = P.vis + (size_t)(fi.view_rank >> 16) * P.W * P.H;
-        // footprints are wide and flat: lanes run along x, four rows per round so that four loads are in flight
+        // footprints are wide and flat: lanes run along x, kOccRows rows per round so that as many loads are in flight
         // before the first wave-wide vote
         bool visible = false;
         for (uint32_t x = fi.x0; x <= fi.x1 && !visible; x += 64) {
             const uint32_t px = min(x + lane, (uint32_t)fi.x1);       // surplus lanes re-test the last column
-            for (uint32_t y = fi.y0; y <= fi.y1; y += 4) {
-                uint32_t d[4];
+            for (uint32_t y = fi.y0; y <= fi.y1; y += kOccRows) {
+                uint32_t d[kOccRows];
 #pragma unroll
-                for (uint32_t k = 0; k < 4; ++k) {
+                for (uint32_t k = 0; k < kOccRows; ++k) {
                     const size_t at = (size_t)min(y + k, (uint32_t)fi.y1) * P.W + px;
                     d[k] = TOPO_CHK(P.counters, at < (size_t)P.W * P.H && (fi.view_rank >> 16) < P.n_views, 6u, at) ? (uint32_t)(vis[at] >> 32) : 0u;
                 }
-                const bool open = d[0] >= fi.zmin_bits || d[1] >= fi.zmin_bits || d[2] >= fi.zmin_bits || d[3] >= fi.zmin_bits;
+                bool open = false;
+#pragma unroll
+                for (uint32_t k = 0; k < kOccRows; ++k) open |= d[k] >= fi.zmin_bits;
                 if (__any(open)) { visible = true; break; }
             }
         }
