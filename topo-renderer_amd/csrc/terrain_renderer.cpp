@@ -400,12 +400,14 @@ int TerrainRenderer::render_frame(FrameCtx& c, hipStream_t stream, uint32_t n, c
     const size_t near_cap = 8 * work_cap;   // a near block is cut into strips of >= 2 cell rows: at most 8
     if (int rc = ensure_on(stream, &c.d_work, &c.cap_work, (near_cap ? near_cap : 1) * sizeof(WorkItem))) return rc;
     if (int rc = ensure_on(stream, &c.d_work2, &c.cap_work2, (near_cap ? near_cap : 1) * sizeof(WorkItem))) return rc;   // far survivors, in strips too
-    if (int rc = ensure_on(stream, &c.d_far, &c.cap_far, (work_cap ? work_cap : 1) * sizeof(FarItem))) return rc;
+    // the far-candidate list: kFarLists sub-lists, cull workgroup b (256 blocks) appending to sub-list b % kFarLists
+    const size_t far_sub_cap = ((work_cap + 255) / 256 + kFarLists - 1) / kFarLists * 256;
+    if (int rc = ensure_on(stream, &c.d_far, &c.cap_far, (far_sub_cap ? far_sub_cap * kFarLists : 1) * sizeof(FarItem))) return rc;
     if (int rc = ensure_on(stream, &c.d_big, &c.cap_big, big_cap * sizeof(BigItem))) return rc;
     if (int rc = ensure_on(stream, &c.d_rare, &c.cap_rare, rare_cap * sizeof(RareItem))) return rc;
     if (!c.d_counters) {
-        if (int rc = ensure_on(stream, &c.d_counters, &c.cap_counters, 16 * sizeof(uint32_t))) return rc;
-        TOPO_HIP_TRY(hipMemsetAsync(c.d_counters, 0, 16 * sizeof(uint32_t), stream));
+        if (int rc = ensure_on(stream, &c.d_counters, &c.cap_counters, kCounterWords * sizeof(uint32_t))) return rc;
+        TOPO_HIP_TRY(hipMemsetAsync(c.d_counters, 0, kCounterWords * sizeof(uint32_t), stream));
     }
     if (!c.h_status) TOPO_HIP_TRY(hipHostMalloc((void**)&c.h_status, kStatusRing * 16 * sizeof(uint32_t)));
     if (c.submitted - c.checked == kStatusRing) {      // nobody has waited for this context's frames for a whole ring: fold them now
@@ -450,6 +452,7 @@ int TerrainRenderer::render_frame(FrameCtx& c, hipStream_t stream, uint32_t n, c
     p.split_m = occlusion_split_m_;
     p.rare_cap = (uint32_t)rare_cap;
     p.work_cap = (uint32_t)work_cap;
+    p.far_sub_cap = (uint32_t)far_sub_cap;
     p.near_cap = (uint32_t)near_cap;
     p.big_cap = (uint32_t)big_cap;
     p.n_views = n;

@@ -52,7 +52,8 @@ struct FrameParams {
     RareItem* rare;
     FarItem* far;              // far candidates (k_cull -> k_occlusion)
     WorkItem* work2;           // far survivors (k_occlusion -> second k_raster)
-    uint32_t work_cap, big_cap, rare_cap;   // work_cap: entries of far / work2 (one per block and view)
+    uint32_t work_cap, big_cap, rare_cap;   // work_cap: entries of work2 (one per block and view)
+    uint32_t far_sub_cap;                   // entries of each of the kFarLists sub-lists of `far` (enough for every candidate its workgroups can produce)
     uint32_t near_cap;                      // entries of work (up to 4 strips per near block)
     float split_m;             // view depth (m) beyond which a block is an occlusion-test candidate; 0 = feature off
     uint32_t n_views, n_tiles;
@@ -77,6 +78,8 @@ struct OutputParams {
 
 constexpr uint32_t kStatusBigOverflow = 1u;    // big-triangle queue full: handled in-lane (slower, still exact)
 constexpr uint32_t kStatusRareOverflow = 2u;   // rare-triangle queue full: triangles were DROPPED -> the frame is invalid
+constexpr uint32_t kFarLists = 64;             // the far-candidate list is kept as 64 sub-lists, each with a counter on a cache line of its own
+constexpr uint32_t kCounterWords = 16 + 16 * kFarLists;      // queue counters and status words of one frame, then the sub-list counters (word 16 + 16 q)
 constexpr uint32_t kStatusBounds = 4u;         // TOPO_BOUNDS_CHECK build only: an out-of-range index was formed (and not used);
                                                // counters[8] = site tag, counters[9..10] = the offending value
 

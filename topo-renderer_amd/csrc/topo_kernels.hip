@@ -334,7 +334,8 @@ __global__ __launch_bounds__(64) void k_normals_border(const TileDev* __restrict
 // A wave takes 64 segments at a time: one coalesced read of their marks, then one 512-byte store per marked segment.
 __global__ __launch_bounds__(256) void k_clear(uint64_t* __restrict__ vis, uint8_t* __restrict__ dirty, size_t n,
                                                uint32_t* __restrict__ counters) {
-    if (blockIdx.x == 0 && threadIdx.x < 16) counters[threadIdx.x] = 0;   // queue counters and this frame's status word
+    if (blockIdx.x == 0)   // queue counters, this frame's status word, the far sub-lists' counters
+        for (uint32_t i = threadIdx.x; i < kCounterWords; i += 256) counters[i] = 0;
     const uint32_t lane = threadIdx.x & 63;
     const size_t nseg = (n + 63) >> 6, wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwave = (size_t)gridDim.x * 4;
     for (size_t g = wave * 64; g < nseg; g += nwave * 64) {
@@ -492,13 +493,16 @@ __global__ __launch_bounds__(256) void k_cull(FrameParams P) {
         if (ix0 > ix1 || iy0 > iy1) continue;       // wholly outside the target even with the margin
         float zf = (float)zmin;
         if ((double)zf > zmin) zf = bits_f(f_bits(zf) - 1u);      // round down
-        const uint32_t slot = atomicAdd(&P.counters[4], 1u);
-        if (slot < P.work_cap) {
+        // 10^5 candidates appended through ONE counter cost this kernel 12 of its 43 us (atomics on one address are served one
+        // at a time, ~12 ns each, however the waves aggregate them): the list is kept as kFarLists sub-lists, workgroup b
+        // appending to sub-list b % kFarLists
+        const uint32_t q = blockIdx.x % kFarLists, slot = atomicAdd(&P.counters[16 + 16 * q], 1u);
+        if (TOPO_CHK(P.counters, slot < P.far_sub_cap, 5u, slot)) {
             FarItem fi;
             fi.view_rank = (view << 16) | rank; fi.block = blk;
             fi.x0 = (uint16_t)ix0; fi.x1 = (uint16_t)ix1; fi.y0 = (uint16_t)iy0; fi.y1 = (uint16_t)iy1;
             fi.zmin_bits = f_bits(zf);
-            P.far[slot] = fi;
+            P.far[(size_t)q * P.far_sub_cap + slot] = fi;
         }
     }
 }
@@ -517,14 +521,29 @@ __global__ __launch_bounds__(256) void k_occlusion(FrameParams P) {
         P.counters[6] = P.counters[1];
         P.counters[7] = P.counters[3];
     }
-    uint32_t count = P.counters[4];
-    if (count > P.work_cap) count = P.work_cap;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave_global = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wave_count = gridDim.x * 4;
-    FarItem fi_next = P.far[wave_global < count ? wave_global : 0u];      // (the next candidate's record is fetched under the current one's scan)
+    // The sub-lists are walked as one list: lane k of every wave holds the number of entries in sub-lists 0 .. k (an inclusive
+    // scan of the 64 counts), entry g of the whole lies in the sub-list q with incl[q - 1] <= g < incl[q].
+    static_assert(kFarLists == 64, "one sub-list per lane");
+    uint32_t incl = min(P.counters[16 + 16 * lane], P.far_sub_cap);
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
+        if ((int)lane >= o) incl += up;
+    }
+    const uint32_t count = (uint32_t)__shfl((int)incl, 63);
+    if (blockIdx.x == 0 && threadIdx.x == 0) P.counters[4] = count;      // the candidate count, for the frame's statistics
+    auto entry = [&](uint32_t g) -> const FarItem& {
+        const uint32_t q = (uint32_t)__popcll(__ballot(incl <= g));      // sub-lists that end at or before g
+        const uint32_t start = q ? (uint32_t)__shfl((int)incl, (int)q - 1) : 0u;
+        return P.far[(size_t)q * P.far_sub_cap + (g - start)];
+    };
+    if (count == 0) return;
+    FarItem fi_next = entry(wave_global < count ? wave_global : 0u);      // (the next candidate's record is fetched under the current one's scan)
     for (uint32_t item = wave_global; item < count; item += wave_count) {
         const FarItem fi = fi_next;
-        fi_next = P.far[item + wave_count < count ? item + wave_count : item];
+        fi_next = entry(item + wave_count < count ? item + wave_count : item);
         const uint64_t* vis = P.vis + (size_t)(fi.view_rank >> 16) * P.W * P.H;
         // footprints are wide and flat: lanes run along x, kOccRows rows per round so that as many loads are in flight
         // before the first wave-wide vote
