@@ -121,11 +121,15 @@ def main():
         return bench_batch(args, T, np, torch, dist, r, locs, deg, SW, PH, rank, world, setup_s)
 
     # ---- load phase (normals K1-K3 over resident heights), timed on its own
-    load_ms = []
+    # (every load-time kernel of the resident tiles is inside the bracket: the per-tile tables of the frame phase -- block
+    # min/max, cull bounds, sin/cos tables: k_block_tables -- and the normals K1-K3)
+    loads = []
     for _ in range(3):
         r.recompute_normals()
-        load_ms.append(r.timings()["load"])
-    load_ms = min(load_ms)
+        tm = r.timings()
+        loads.append((tm["load"], tm["load_tables"]))
+    load_ms, load_tables_ms = min(loads)
+    load_normals_ms = load_ms - load_tables_ms
 
     # ---- outputs: the sector-major strip of the C ABI (topo_render_panorama): strip[8][PH][SW][4], rank g's sectors
     # [8g/N, 8(g+1)/N) one contiguous block.  A rank renders ALL its sectors in one submission (one set of kernel launches:
@@ -196,19 +200,12 @@ def main():
             step()
         fence()
         return
-    kernel_ms = {k: 0.0 for k in (dom, "total")}
-    timed_frames = 0
+    # The timed region: exactly `steps` submissions between two fences, nothing in it waits for a frame.  The HIP-event
+    # durations of its frames' kernels (the events sit on the stream the kernels are launched on) are read AFTER the region
+    # from the renderer's event ring (topo_get_timing_history: the last 32 frames per frame in flight).
     t_start = time.perf_counter()
     for _ in range(args.steps):
         step()
-        # HIP-event durations of a step's kernels (the events sit on the stream the kernels are launched on).  One frame in
-        # flight: this step's (reading them waits for it, which the next submission's host-side staging does anyway);
-        # pipelined: those of the oldest frame in flight, so that reading them does not drain the pipeline
-        tm = r.timings()
-        if tm["total"] > 0.0:
-            timed_frames += 1
-            for k in kernel_ms:
-                kernel_ms[k] += tm[k]
     fence()
     elapsed = time.perf_counter() - t_start
     if dist is not None:
@@ -216,9 +213,10 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     ms_per_step = 1e3 * elapsed / args.steps
-    for k in kernel_ms:
-        kernel_ms[k] /= max(1, timed_frames)
-    timed_ms = dict(kernel_ms)
+    hist = [h for h in r.timing_history(min(args.steps, 32 * depth_frames)) if h["total"] > 0.0]
+    timed_frames = len(hist)
+    timed_ms = {k: (sum(h[k] for h in hist) / timed_frames if timed_frames else 0.0) for k in (dom, "total")}       # means: what the roofline uses
+    timed_median = {k: (sorted(h[k] for h in hist)[timed_frames // 2] if timed_frames else 0.0) for k in (dom, "total")}
     kernel_ms = dict(detail)                 # the table: all events on (a separate pass) ...
     kernel_ms[dom] = timed_ms[dom]           # ... except the dominant kernel and the total: the timed region's
     kernel_ms["total"] = timed_ms["total"]
@@ -303,8 +301,18 @@ def main():
         "kernel_ms": {k: round(v, 4) for k, v in kernel_ms.items()},
         "kernel_ms_note": f"'{dom}' and 'total': HIP events in the timed region (only those events are recorded there); the other "
                           f"kernels: medians of a separate pass of {n_detail} frames with all timing events on (total then {round(detail['total'], 4)} ms)",
+        "gpu_ms_per_step": {"mean": round(timed_ms["total"], 4), "median": round(timed_median["total"], 4), dom + "_median": round(timed_median[dom], 4),
+                            "frames": timed_frames, "what": "first to last HIP event of a frame of the timed region (topo_get_timing_history, read after the region)"},
         "load_ms": round(load_ms, 4),
+        "load_what": "every load-time kernel of the resident tiles: k_block_tables (block min/max, cull bounds, sin/cos tables: this design's own) + normals K1-K3",
+        "load_tables_ms": round(load_tables_ms, 4),
+        "load_normals_ms": round(load_normals_ms, 4),
+        "load_normals_GBps": round(8.0 * n_tiles * TILE * TILE / (load_normals_ms / 1e3) / 1e9, 1) if load_normals_ms > 0 else None,
+        "load_normals_frac_hbm_peak": round(8.0 * n_tiles * TILE * TILE / (load_normals_ms / 1e3) / 1e9 / HBM_PEAK_GBPS, 4) if load_normals_ms > 0 else None,
         "load_GBps": round(8.0 * n_tiles * TILE * TILE / (load_ms / 1e3) / 1e9, 1) if load_ms > 0 else None,
+        "load_GBps_what": "SURVEY 8(d) load-phase bytes (4 B read + 4 B written per texel) over the WHOLE load phase incl. the tables kernel (which reads the DEM a second time)",
+        "add_terrain_ms_per_tile": round(1e3 * upload_s / n_tiles, 3),
+        "add_terrain_what": "topo_add_terrain per tile from pageable host memory: one pooled allocation, the 5.76 MB upload, tables + normals + seam passes, one stream sync",
         "hbm_read_roofline_frac_frame": round((4.0 * n_tiles * TILE * TILE / (ms_per_step / 1e3) / 1e9) / HBM_PEAK_GBPS, 5),
         "counters": counters,
         "terrain_pixel_frac": round(float((depth < 1.0).float().mean().item()), 4),   # this rank's sectors

@@ -222,9 +222,15 @@ int topo_set_occlusion_split(topo_ctx* ctx, float metres);
 
 /* Per-kernel durations (ms, HIP events on the context's stream) of the last topo_render* call:
  * [0] clear  [1] cull  [2] raster (both phases)  [3] occlusion test  [4] raster_rare + raster_big (both phases)
- * [5] resolve+post  [6] total; of the last topo_recompute_normals: [7] load phase.  Synchronises. */
-#define TOPO_TIMING_SLOTS 8
+ * [5] resolve+post  [6] total; of the last topo_recompute_normals: [7] the load phase -- every load-time kernel of the
+ * resident tiles: the per-tile tables of the frame phase (block min/max, cull bounds, sin/cos tables) and the normals K1-K3 --
+ * and [8] its tables part alone.  Synchronises. */
+#define TOPO_TIMING_SLOTS 9
 int topo_get_timings(topo_ctx* ctx, float out_ms[TOPO_TIMING_SLOTS]);
+/* The same durations of the last `n_frames` frames (each context keeps the events of its last 32), oldest first:
+ * out_ms[7 * i + k] = slot [k] (k = 0..6) of frame i, *n_out = frames written.  Waits for the frames in flight, so it is
+ * called AFTER a timed region: nothing inside the region has to wait for a frame just to learn its kernels' durations. */
+int topo_get_timing_history(topo_ctx* ctx, uint32_t n_frames, float* out_ms, uint32_t* n_out);
 /* Which of the slots [0]..[5] to measure (bit i = slot i; default all).  Every timing event between two kernels leaves the
  * GPU idle for ~6 us while the marker completes -- 4 % of a c4 frame, a third of a c1 frame with all nine events -- so a
  * caller that only wants one kernel's duration (bench.py: the dominant one) or none selects just that; unselected slots

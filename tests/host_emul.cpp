@@ -187,8 +187,10 @@ int emul_render(const EmulTile* tiles, uint32_t n_tiles, uint32_t tile_w, uint32
             f3 wpos = {0.0f, 0.0f, 0.0f}, wnrm;
             if (g_split) {      // the two-step route k_resolve takes for waves whose pixels share few winners
                 TriRecord rec;
-                resolve_setup(td[rank], tile_w, div_hm1, tile_h - 1, view, W, H, tri, fan, ndec, rec);
-                if (!resolve_pixel(rec, W, H, px, py, wpos.x, wpos.y, wnrm)) return -1;
+                // the reference pixel k_resolve uses: the origin of the 64 x 4 px strip the pixel lies in
+                const int32_t ox = px & ~63, oy = py & ~3;
+                resolve_setup(td[rank], tile_w, div_hm1, tile_h - 1, view, W, H, tri, fan, ndec, ox, oy, rec);
+                if (!resolve_pixel(rec, pixel_at(W, H, px, py, ox, oy), wpos.x, wpos.y, wnrm)) return -1;
             } else if (!resolve_varyings(td[rank], tile_w, div_hm1, tile_h - 1, view, W, H, tri, fan, ndec, px, py, wpos, wnrm)) return -1;
             shade_fragment(view.view_mode, {view.sun[0], view.sun[1], view.sun[2]}, view.cam_x, view.cam_y, (float)px + 0.5f,
                            (float)py + 0.5f, wpos, wnrm, lin);

@@ -28,8 +28,8 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "topo_hip.h")
 TOPO_OK = 0
 TOPO_ERR_INVALID, TOPO_ERR_UNSUPPORTED, TOPO_ERR_HIP, TOPO_ERR_NOT_FOUND, TOPO_ERR_CAPACITY = -1, -2, -3, -4, -5
 FORMAT_RGBA8_UNORM_SRGB, FORMAT_BGRA8_UNORM_SRGB, FORMAT_RGBA8_UNORM, FORMAT_BGRA8_UNORM = 1, 2, 3, 4
-TIMING_SLOTS = 8
-TIMING_NAMES = ("clear", "cull", "raster", "occlusion", "raster_big", "resolve", "total", "load")
+TIMING_SLOTS = 9
+TIMING_NAMES = ("clear", "cull", "raster", "occlusion", "raster_big", "resolve", "total", "load", "load_tables")
 
 NEAR, FAR = 50.0, 500000.0           # data/camera.rs:6-7
 N_SECTORS = 8                        # fixed panorama sector count
@@ -91,6 +91,7 @@ def lib():
             "topo_set_normals_lds_rows": (C.c_int, [vp, C.c_int]),
             "topo_debug_set_queue_caps": (C.c_int, [vp, u32, u32]),
             "topo_get_timings": (C.c_int, [vp, vp]),
+            "topo_get_timing_history": (C.c_int, [vp, C.c_uint32, vp, vp]),
             "topo_get_counters": (C.c_int, [vp, vp]),
             "topo_set_occlusion_split": (C.c_int, [vp, f32]),
             "topo_set_timing_slots": (C.c_int, [vp, u32]),
@@ -483,6 +484,12 @@ class TerrainRenderer:
         out = np.zeros(TIMING_SLOTS, np.float32)
         self._check(lib().topo_get_timings(self._h, _p(out)))
         return {k: float(v) for k, v in zip(TIMING_NAMES, out) if k != "_"}
+
+    def timing_history(self, n_frames: int) -> list:
+        """Per-kernel durations of the last n_frames frames (at most 32 per frame in flight), oldest first; waits for them."""
+        out, n = np.zeros((max(1, n_frames), 7), np.float32), C.c_uint32(0)
+        self._check(lib().topo_get_timing_history(self._h, n_frames, _p(out), C.byref(n)))
+        return [{k: float(v) for k, v in zip(TIMING_NAMES[:7], row)} for row in out[:n.value]]
 
     def counters(self) -> dict:
         out = np.zeros(6, np.uint32)

@@ -56,8 +56,9 @@ int TerrainRenderer::create(TerrainRenderer** out, int device, uint32_t w, uint3
     r->format_ = format;
     e = hipSetDevice(device);
     if (e == hipSuccess) e = hipStreamCreate(&r->own_stream_);
-    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreate(&r->load_ev_[i]);
-    for (int i = 0; i < kNumEvents && e == hipSuccess; ++i) e = hipEventCreate(&r->ctx_[0].ev[i]);
+    for (int i = 0; i < 3 && e == hipSuccess; ++i) e = hipEventCreate(&r->load_ev_[i]);
+    for (int k = 0; k < kEvRing && e == hipSuccess; ++k)
+        for (int i = 0; i < kNumEvents && e == hipSuccess; ++i) e = hipEventCreate(&r->ctx_[0].evr[k][i]);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&r->ctx_[0].done, hipEventDisableTiming);
     if (e != hipSuccess) {
         *err = std::string("HIP initialisation failed: ") + hipGetErrorString(e);
@@ -75,9 +76,7 @@ TerrainRenderer::~TerrainRenderer() {
     for (auto& c : ctx_)
         if (c.stream) (void)hipStreamSynchronize(c.stream);
     for (auto& kv : tiles_) {
-        (void)hipFree(kv.second.d_heights);
-        (void)hipFree(kv.second.d_normals);
-        (void)hipFree(kv.second.d_minmax);
+        (void)hipFree(kv.second.d_pool);
     }
     void* bufs[] = {d_tiles_, d_views_, d_out_rgba_, d_out_depth_, d_edge_jobs_, d_corner_jobs_, d_peaks_, d_proj_, d_overlay_geo_, d_overlay_keys_};
     for (void* p : bufs)
@@ -86,8 +85,9 @@ TerrainRenderer::~TerrainRenderer() {
         void* cb[] = {c.d_vis, c.d_dirty, c.d_work, c.d_work2, c.d_far, c.d_big, c.d_rare, c.d_counters};
         for (void* p : cb)
             if (p) (void)hipFree(p);
-        for (auto& e : c.ev)
-            if (e) (void)hipEventDestroy(e);
+        for (auto& set : c.evr)
+            for (auto& e : set)
+                if (e) (void)hipEventDestroy(e);
         if (c.done) (void)hipEventDestroy(c.done);
         if (c.stream) (void)hipStreamDestroy(c.stream);
         if (c.h_status) (void)hipHostFree(c.h_status);
@@ -197,16 +197,20 @@ int TerrainRenderer::add_terrain(int32_t lat, int32_t lon, const float* heights,
     t.lat = lat;
     t.lon = lon;
     t.seq = next_seq_++;
-    TOPO_HIP_TRY(hipMalloc((void**)&t.d_heights, texels * 4));
-    hipError_t e = hipMalloc((void**)&t.d_normals, texels * 4);
-    // one allocation: block min/max (2 floats per block), then the sin/cos tables of the w columns and the h rows
-    const size_t tile_floats = (size_t)bxc * byc * 2 + 2 * ((size_t)w + h);   // even: the f64 block bounds that follow stay 8-byte aligned
-    if (e == hipSuccess) e = hipMalloc((void**)&t.d_minmax, tile_floats * sizeof(float) + (size_t)bxc * byc * 17 * sizeof(double));   // sphere 4 + corners 12 + sagitta 1
-    if (e == hipSuccess) e = hipMemcpyAsync(t.d_heights, heights, texels * 4, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream_);
+    // ONE allocation per tile: heights, normals, then block min/max (2 floats per block), the sin/cos tables of the w columns
+    // and the h rows, and the f64 cull bounds (sphere 4 + corners 12 + sagitta 1 doubles per block); every part 256-byte aligned
+    const size_t tile_floats = (size_t)bxc * byc * 2 + 2 * ((size_t)w + h);
+    auto up256 = [](size_t n) { return (n + 255) & ~(size_t)255; };
+    const size_t off_normals = up256(texels * 4), off_tables = off_normals + up256(texels * 4), off_bounds = off_tables + up256(tile_floats * sizeof(float));
+    TOPO_HIP_TRY(hipMalloc(&t.d_pool, off_bounds + (size_t)bxc * byc * 17 * sizeof(double)));
+    t.d_heights = reinterpret_cast<float*>(t.d_pool);
+    t.d_normals = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(t.d_pool) + off_normals);
+    t.d_minmax = reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(t.d_pool) + off_tables);
+    const hipError_t e = hipMemcpyAsync(t.d_heights, heights, texels * 4, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream_);
     // (the zero-initialised normal texture: k_normals_interior writes the untouched border ring as zero)
     if (e != hipSuccess) {
-        (void)hipFree(t.d_heights); (void)hipFree(t.d_normals); (void)hipFree(t.d_minmax);
-        return hip_fail(e, "tile allocation/upload");
+        (void)hipFree(t.d_pool);
+        return hip_fail(e, "tile upload");
     }
     // TerrainUniforms::new (render/data.rs:124-151)
     t.dev.heights = t.d_heights;
@@ -214,12 +218,11 @@ int TerrainRenderer::add_terrain(int32_t lat, int32_t lon, const float* heights,
     t.dev.block_minmax = t.d_minmax;
     t.dev.trig_lon = t.d_minmax + (size_t)bxc * byc * 2;
     t.dev.trig_lat = t.dev.trig_lon + 2 * (size_t)w;
-    t.dev.block_bounds = reinterpret_cast<const double*>(t.d_minmax + tile_floats);
+    t.dev.block_bounds = reinterpret_cast<const double*>(reinterpret_cast<uint8_t*>(t.d_pool) + off_bounds);
     t.dev.raster_x = rp[0]; t.dev.raster_y = rp[1];
     t.dev.model_x = mp[0]; t.dev.model_y = mp[1];
     t.dev.scale_x = ps[0]; t.dev.scale_y = ps[1];
     terrain_rotation(mp[0], mp[1], t.dev.rot);
-    launch_block_minmax(t.dev, w, h, stream_);
     // BTreeMap::insert replaces an existing entry; its GPU resources are dropped after the passes below
     Tile old{};
     bool had_old = false;
@@ -232,13 +235,14 @@ int TerrainRenderer::add_terrain(int32_t lat, int32_t lon, const float* heights,
         std::vector<EdgeJob> edges;
         std::vector<CornerJob> corners;
         collect_jobs(nt, rk, edges, corners);
+        launch_block_tables((const TileDev*)d_tiles_, rk.at(geo_key(lat, lon)), 1, tile_w_, tile_h_, stream_);
         launch_normals_interior((const TileDev*)d_tiles_, rk.at(geo_key(lat, lon)), 1, tile_w_, tile_h_, lds_rows_, stream_);
         if (int rc = run_seam_jobs(edges, corners)) return rc;
     }
     TOPO_HIP_TRY(hipStreamSynchronize(stream_));   // `heights` (and the job lists) are only borrowed for the call
     if (had_old) {
         TOPO_HIP_TRY(hipStreamSynchronize(stream_));
-        (void)hipFree(old.d_heights); (void)hipFree(old.d_normals); (void)hipFree(old.d_minmax);
+        (void)hipFree(old.d_pool);
     }
     TOPO_HIP_TRY(hipGetLastError());
     return TOPO_OK;
@@ -250,7 +254,7 @@ int TerrainRenderer::unload_terrain(int32_t lat, int32_t lon) {
     if (!t) return TOPO_OK;   // BTreeMap::remove of a missing key is a no-op
     if (int rc = join()) return rc;
     TOPO_HIP_TRY(hipStreamSynchronize(stream_));
-    (void)hipFree(t->d_heights); (void)hipFree(t->d_normals); (void)hipFree(t->d_minmax);
+    (void)hipFree(t->d_pool);
     tiles_.erase(geo_key(lat, lon));
     table_dirty_ = true;
     return TOPO_OK;
@@ -269,7 +273,11 @@ int TerrainRenderer::recompute_normals() {
     if (int rc = ensure(&d_edge_jobs_, &cap_edge_jobs_, (edges.size() + 1) * sizeof(EdgeJob))) return rc;
     if (int rc = ensure(&d_corner_jobs_, &cap_corner_jobs_, (corners.size() + 1) * sizeof(CornerJob))) return rc;
     if (int rc = upload_seam_jobs(edges, corners)) return rc;      // (the job lists: host -> device, ahead of the kernels that are timed)
+    // the whole load phase of the resident tiles, every load-time kernel inside the bracket: the tables of the frame phase
+    // (ev 0 -> 2), then the normals K1-K3 (ev 2 -> 1)
     TOPO_HIP_TRY(hipEventRecord(load_ev_[0], stream_));
+    launch_block_tables((const TileDev*)d_tiles_, 0, (uint32_t)order.size(), tile_w_, tile_h_, stream_);
+    TOPO_HIP_TRY(hipEventRecord(load_ev_[2], stream_));
     launch_normals_interior((const TileDev*)d_tiles_, 0, (uint32_t)order.size(), tile_w_, tile_h_, lds_rows_, stream_);
     launch_seam_jobs(edges.size(), corners.size());
     TOPO_HIP_TRY(hipEventRecord(load_ev_[1], stream_));
@@ -307,7 +315,9 @@ int TerrainRenderer::upload_tile_table() {
 
 int TerrainRenderer::init_ctx(FrameCtx& c, bool own_stream) {
     if (!c.done) {
-        for (auto& e : c.ev) TOPO_HIP_TRY(hipEventCreate(&e));
+        for (auto& set : c.evr)
+            for (auto& e : set)
+                if (!e) TOPO_HIP_TRY(hipEventCreate(&e));
         TOPO_HIP_TRY(hipEventCreateWithFlags(&c.done, hipEventDisableTiming));
     }
     if (own_stream && !c.stream) TOPO_HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
@@ -495,31 +505,35 @@ int TerrainRenderer::render_frame(FrameCtx& c, hipStream_t stream, uint32_t n, c
                 for (int st = 0; st < 8; ++st)
                     if (stages_of_slot[sl] & (1u << st)) ev_need |= (3u << st);
     }
-    c.ev_recorded = ev_need;
-    c.slots = timing_slots_;
-    if (ev_need & (1u << 0)) TOPO_HIP_TRY(hipEventRecord(c.ev[0], stream));
+    const int ring = (int)(c.frames % kEvRing);
+    hipEvent_t* const ev = c.evr[ring];
+    c.evr_recorded[ring] = ev_need;
+    c.evr_slots[ring] = timing_slots_;
+    c.evr_frame[ring] = ++frame_seq_;
+    ++c.frames;
+    if (ev_need & (1u << 0)) TOPO_HIP_TRY(hipEventRecord(ev[0], stream));
     launch_clear(p, stream);
-    if (ev_need & (1u << 1)) TOPO_HIP_TRY(hipEventRecord(c.ev[1], stream));
+    if (ev_need & (1u << 1)) TOPO_HIP_TRY(hipEventRecord(ev[1], stream));
     launch_cull(p, stream);
-    if (ev_need & (1u << 2)) TOPO_HIP_TRY(hipEventRecord(c.ev[2], stream));
+    if (ev_need & (1u << 2)) TOPO_HIP_TRY(hipEventRecord(ev[2], stream));
     launch_raster(p, 0, stream);
-    if (ev_need & (1u << 3)) TOPO_HIP_TRY(hipEventRecord(c.ev[3], stream));
+    if (ev_need & (1u << 3)) TOPO_HIP_TRY(hipEventRecord(ev[3], stream));
     launch_raster_rare(p, stream);
     launch_raster_big(p, stream);
-    if (ev_need & (1u << 4)) TOPO_HIP_TRY(hipEventRecord(c.ev[4], stream));
+    if (ev_need & (1u << 4)) TOPO_HIP_TRY(hipEventRecord(ev[4], stream));
     if (p.split_m > 0.0f) {
         launch_occlusion(p, stream);
     }
-    if (ev_need & (1u << 5)) TOPO_HIP_TRY(hipEventRecord(c.ev[5], stream));
+    if (ev_need & (1u << 5)) TOPO_HIP_TRY(hipEventRecord(ev[5], stream));
     if (p.split_m > 0.0f) launch_raster(p, 1, stream);
-    if (ev_need & (1u << 6)) TOPO_HIP_TRY(hipEventRecord(c.ev[6], stream));
+    if (ev_need & (1u << 6)) TOPO_HIP_TRY(hipEventRecord(ev[6], stream));
     if (p.split_m > 0.0f) {
         launch_raster_rare(p, stream);
         launch_raster_big(p, stream);
     }
-    if (ev_need & (1u << 7)) TOPO_HIP_TRY(hipEventRecord(c.ev[7], stream));
+    if (ev_need & (1u << 7)) TOPO_HIP_TRY(hipEventRecord(ev[7], stream));
     launch_resolve(p, out, stream);
-    if (ev_need & (1u << 8)) TOPO_HIP_TRY(hipEventRecord(c.ev[8], stream));
+    if (ev_need & (1u << 8)) TOPO_HIP_TRY(hipEventRecord(ev[8], stream));
     // this frame's counters (queue fills, status bits), for whoever waits for the frame (check_frames, get_counters)
     TOPO_HIP_TRY(hipMemcpyAsync(c.h_status + (c.submitted % kStatusRing) * 16, c.d_counters, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     ++c.submitted;
@@ -712,34 +726,69 @@ int TerrainRenderer::set_queue_caps(uint32_t big_cap, uint32_t rare_cap) {
     return join();
 }
 
+// Durations of the frame whose events are set `ring` of context c (out[0..6]; the frame must have completed).
+int TerrainRenderer::frame_durations(FrameCtx& c, int ring, float out[7]) {
+    hipEvent_t* ev = c.evr[ring];
+    float d[8];
+    for (int i = 0; i < 8; ++i) {
+        d[i] = 0.0f;
+        if ((c.evr_recorded[ring] >> i & 3u) == 3u) TOPO_HIP_TRY(hipEventElapsedTime(&d[i], ev[i], ev[i + 1]));
+    }
+    out[0] = d[0];                // clear
+    out[1] = d[1];                // cull
+    out[2] = d[2] + d[5];         // raster: near blocks + far survivors
+    out[3] = d[4];                // occlusion test
+    out[4] = d[3] + d[6];         // rare + big (both phases)
+    out[5] = d[7];                // resolve
+    for (int sl = 0; sl < 6; ++sl)
+        if (!(c.evr_slots[ring] & (1u << sl))) out[sl] = 0.0f;      // (a neighbour's events may have bracketed it by chance)
+    TOPO_HIP_TRY(hipEventElapsedTime(&out[6], ev[0], ev[8]));
+    return TOPO_OK;
+}
+
 int TerrainRenderer::get_timings(float out[TOPO_TIMING_SLOTS]) {
     for (int i = 0; i < TOPO_TIMING_SLOTS; ++i) out[i] = 0.0f;
     if (int rc = bind_device()) return rc;
     // depth 1: the last frame.  Pipelined: the OLDEST frame in flight (the context the next submission will reuse), so
     // that reading timings every frame does not wait for the frame just submitted
     FrameCtx& c = ctx_[pipeline_depth_ > 1 ? next_ctx_ : last_ctx_];
-    hipEvent_t* ev_ = c.ev;
-    if (c.timed) {
-        TOPO_HIP_TRY(hipEventSynchronize(ev_[8]));
-        float d[8];
-        for (int i = 0; i < 8; ++i) {
-            d[i] = 0.0f;
-            if ((c.ev_recorded >> i & 3u) == 3u) TOPO_HIP_TRY(hipEventElapsedTime(&d[i], ev_[i], ev_[i + 1]));
-        }
-        out[0] = d[0];                // clear
-        out[1] = d[1];                // cull
-        out[2] = d[2] + d[5];         // raster: near blocks + far survivors
-        out[3] = d[4];                // occlusion test
-        out[4] = d[3] + d[6];         // rare + big (both phases)
-        out[5] = d[7];                // resolve
-        for (int sl = 0; sl < 6; ++sl)
-            if (!(c.slots & (1u << sl))) out[sl] = 0.0f;      // (a neighbour's events may have bracketed it by chance)
-        TOPO_HIP_TRY(hipEventElapsedTime(&out[6], ev_[0], ev_[8]));
+    if (c.timed && c.frames) {
+        const int ring = (int)((c.frames - 1) % kEvRing);
+        TOPO_HIP_TRY(hipEventSynchronize(c.evr[ring][8]));
+        if (int rc = frame_durations(c, ring, out)) return rc;
     }
     if (load_timed_) {
         TOPO_HIP_TRY(hipEventSynchronize(load_ev_[1]));
-        TOPO_HIP_TRY(hipEventElapsedTime(&out[7], load_ev_[0], load_ev_[1]));
+        TOPO_HIP_TRY(hipEventElapsedTime(&out[7], load_ev_[0], load_ev_[1]));      // the whole load phase
+        TOPO_HIP_TRY(hipEventElapsedTime(&out[8], load_ev_[0], load_ev_[2]));      // its tables part
     }
+    return TOPO_OK;
+}
+
+// The last n_frames frames (at most kEvRing per context), oldest first, 7 durations each (slots [0]..[6] of topo_get_timings).
+// Waits for the frames in flight: meant to be called after a timed region, not inside it.
+int TerrainRenderer::get_timing_history(uint32_t n_frames, float* out_ms, uint32_t* n_out) {
+    *n_out = 0;
+    if (!out_ms && n_frames) return fail(TOPO_ERR_INVALID, "null argument");
+    if (int rc = join()) return rc;
+    TOPO_HIP_TRY(hipStreamSynchronize(stream_));
+    struct Ref { uint64_t frame; int ctx, ring; };
+    std::vector<Ref> refs;
+    for (int ci = 0; ci < kMaxPipeline; ++ci) {
+        FrameCtx& c = ctx_[ci];
+        const uint64_t have = c.frames < (uint64_t)kEvRing ? c.frames : (uint64_t)kEvRing;
+        for (uint64_t k = 0; k < have; ++k) {
+            const int ring = (int)((c.frames - 1 - k) % kEvRing);
+            refs.push_back(Ref{c.evr_frame[ring], ci, ring});
+        }
+    }
+    std::sort(refs.begin(), refs.end(), [](const Ref& a, const Ref& b) { return a.frame < b.frame; });
+    const size_t n = std::min<size_t>(n_frames, refs.size());
+    for (size_t i = 0; i < n; ++i) {
+        const Ref& r = refs[refs.size() - n + i];
+        if (int rc = frame_durations(ctx_[r.ctx], r.ring, out_ms + 7 * i)) return rc;
+    }
+    *n_out = (uint32_t)n;
     return TOPO_OK;
 }
 

@@ -35,6 +35,7 @@ struct Tile {          // RenderBuffer (render_buffer.rs:23-31) minus the wgpu p
     float* d_heights = nullptr;
     uint32_t* d_normals = nullptr;
     float* d_minmax = nullptr;
+    void* d_pool = nullptr;         // the one allocation the three pointers above point into
     TileDev dev{};
 };
 
@@ -69,6 +70,7 @@ class TerrainRenderer {
     int set_normals_lds_rows(int rows);
     int set_queue_caps(uint32_t big_cap, uint32_t rare_cap);
     int get_timings(float out[TOPO_TIMING_SLOTS]);
+    int get_timing_history(uint32_t n_frames, float* out_ms, uint32_t* n_out);
     int get_counters(uint32_t out[6]);
     int frame_status(uint32_t out[4]);
     int set_occlusion_split(float metres);
@@ -118,7 +120,9 @@ class TerrainRenderer {
 
     hipStream_t own_stream_ = nullptr, stream_ = nullptr;
     static constexpr int kNumEvents = 9;
-    hipEvent_t load_ev_[2] = {};
+    static constexpr int kEvRing = 32;
+    uint64_t frame_seq_ = 0;          // frames submitted by this renderer
+    hipEvent_t load_ev_[3] = {};      // recompute_normals: start, end, between the tables and the normals
     bool load_timed_ = false;
 
     // Everything one frame in flight owns.  With pipeline depth 1 (default) there is one context and it runs on
@@ -126,14 +130,18 @@ class TerrainRenderer {
     // that the memory-latency-bound cull/raster phases of one frame run under the ALU-bound resolve of the previous one.
     struct FrameCtx {
         hipStream_t stream = nullptr;        // own stream (depth > 1)
-        hipEvent_t ev[kNumEvents] = {};
+        // timing events of the last kEvRing frames of this context (a frame's durations stay readable while later frames are
+        // submitted: topo_get_timing_history reads a whole timed region's frames after it, without a wait inside it)
+        hipEvent_t evr[kEvRing][kNumEvents] = {};
+        uint32_t evr_recorded[kEvRing] = {}, evr_slots[kEvRing] = {};
+        uint64_t evr_frame[kEvRing] = {};     // the renderer-wide number of the frame that used the set
+        uint64_t frames = 0;                  // frames submitted on this context
         hipEvent_t done = nullptr;
         bool timed = false, pending = false;
         // pinned ring of the last kStatusRing frames' 16 counter words, each copied out in stream order behind its k_resolve;
         // frames [checked, submitted) have not been looked at by check_frames yet
         uint32_t* h_status = nullptr;
         uint64_t submitted = 0, checked = 0;
-        uint32_t ev_recorded = 0, slots = 0;  // which of ev[] the last frame recorded, for which timing slots
         void* d_vis = nullptr;      size_t cap_vis = 0;
         void* d_dirty = nullptr;    size_t cap_dirty = 0;   // one mark per 64 visibility keys (topo_kernels.hip: struct Vis)
         void* d_work = nullptr;     size_t cap_work = 0;
@@ -154,6 +162,7 @@ class TerrainRenderer {
     bool overflow_pending_ = false;
     int ensure_on(hipStream_t s, void** p, size_t* cap, size_t need);
     int render_frame(FrameCtx& c, hipStream_t s, uint32_t n, const topo_uniforms* views, uint32_t w, uint32_t h, const OutputParams& out);
+    int frame_durations(FrameCtx& c, int ring, float out[7]);
 
     // grow-only device buffers
     void* d_tiles_ = nullptr;    size_t cap_tiles_ = 0;

@@ -131,6 +131,12 @@ int topo_get_timings(topo_ctx* ctx, float out_ms[TOPO_TIMING_SLOTS]) {
     TOPO_CALL(ctx->r->get_timings(out_ms));
 }
 
+int topo_get_timing_history(topo_ctx* ctx, uint32_t n_frames, float* out_ms, uint32_t* n_out) {
+    TOPO_GUARD(ctx);
+    if (!n_out) return TOPO_ERR_INVALID;
+    TOPO_CALL(ctx->r->get_timing_history(n_frames, out_ms, n_out));
+}
+
 int topo_set_timing_slots(topo_ctx* ctx, uint32_t slot_mask) {
     TOPO_GUARD(ctx);
     TOPO_CALL(ctx->r->set_timing_slots(slot_mask));

@@ -96,7 +96,7 @@ struct CornerJob {         // compute_normals_corner (compute_normals_corner_sha
     uint32_t uni;
 };
 
-void launch_block_minmax(const TileDev& tile, uint32_t w, uint32_t h, hipStream_t s);   // + the tile's sin/cos tables
+void launch_block_tables(const TileDev* tiles, uint32_t first, uint32_t count, uint32_t w, uint32_t h, hipStream_t s);   // block min/max, cull bounds, sin/cos tables of `count` tiles
 // interior normals of tiles[first .. first+count); also zeroes their border ring (fresh Rgba8Unorm texture)
 void launch_normals_interior(const TileDev* tiles, uint32_t first, uint32_t count, uint32_t w, uint32_t h, int lds_rows,
                              hipStream_t s);

@@ -1,6 +1,6 @@
 // topo_kernels.hip -- gfx950 (CDNA4, wave64) kernels of the terrain path.
 //
-//   load phase   k_tiff_rows (GeoTIFF predictor / layout), k_block_minmax (+ per-tile sin/cos tables and cull bounds),
+//   load phase   k_tiff_rows (GeoTIFF predictor / layout), k_block_tables (block min/max, cull bounds, per-tile sin/cos tables),
 //                k_normals_interior<ROWS>, k_normals_border (seams + corners) (compute_normals*.wgsl; once per add_terrain)
 //   frame phase  k_clear -> k_cull -> [near] k_raster -> k_raster_rare -> k_raster_big -> k_occlusion ->
 //                [far survivors] k_raster -> k_raster_rare -> k_raster_big -> k_resolve
@@ -86,74 +86,138 @@ __device__ __forceinline__ void vis_min(const Vis& v, size_t pix, uint64_t key) 
 struct SinCos64 { double s, c; };
 __device__ __forceinline__ SinCos64 sincos64(double a) { SinCos64 r; r.s = sin(a); r.c = cos(a); return r; }
 
-// min/max height of the (kVX x kVY) vertices of every raster block, one wave per block; the first (w + h) / 64
-// waves also fill one entry each of the tile's sin/cos tables (TileDev::trig_lon / trig_lat).
-__global__ __launch_bounds__(64) void k_block_minmax(TileDev t, uint32_t w, uint32_t h, uint32_t bx_count) {
-    const uint32_t blk = blockIdx.x, bx = blk % bx_count, by = blk / bx_count;
-    const uint32_t x = bx * kBCX + threadIdx.x;
-    float mn = INFINITY, mx = -INFINITY;
-    if (threadIdx.x < kVX && x < w) {
-        for (uint32_t r = 0; r < kVY; ++r) {
-            const uint32_t y = by * kBCY + r;
-            if (y >= h) break;
-            const float v = t.heights[(size_t)y * w + x];
-            mn = fminf(mn, v);
-            mx = fmaxf(mx, v);
-        }
-    }
+// Per-tile tables of the frame phase, for a batch of tiles (blockIdx.y) in ONE launch: min/max height of the (kVX x kVY)
+// vertices of every raster block, the view-independent half of the cull (f64: the block's bounding sphere, the unit directions
+// of its four corners, the sagitta of its patch), and the tile's sin/cos tables (TileDev::trig_lon / trig_lat).
+// One WAVE per run of four horizontally adjacent raster blocks (241 vertex columns x 16 vertex rows): lane i keeps the column
+// minima / maxima of columns i, i + 64, i + 128, i + 192 while the rows stream by as coalesced 256-byte reads (the DEM is
+// read once, at HBM speed; round 2 launched one 64-thread workgroup per block and tile after tile: 19 us per tile, 0.3 TB/s),
+// the 61-column ranges of the four blocks are reduced through a wave-private LDS strip, the fifteen f64 sin/cos pairs the four
+// blocks need (three latitudes, twelve longitudes) are evaluated by fifteen lanes at once instead of six per block one after
+// the other on lane 0, and lanes 0..3 finish one block each.  Same expressions, same results as the one-block-per-wave form.
+constexpr uint32_t kTblBlocks = 4;                                  // raster blocks per wave
+constexpr uint32_t kTblCols = kTblBlocks * kBCX + 1;                // 241 vertex columns
+static_assert(kTblCols <= 256, "four column slots per lane");
+__global__ __launch_bounds__(256) void k_block_tables(const TileDev* __restrict__ tiles, uint32_t first, uint32_t w, uint32_t h, uint32_t bx_count,
+                                                      uint32_t by_count) {
+    __shared__ float s_mn[4][256], s_mx[4][256];
+    __shared__ double s_sc[4][15][2];
+    const TileDev& t = tiles[first + blockIdx.y];
+    const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t runs_per_row = (bx_count + kTblBlocks - 1) / kTblBlocks, n_runs = runs_per_row * by_count;
+    const uint32_t blocks_per_tile = bx_count * by_count;
+    const auto heights = TOPO_GLOBAL_F32(t.heights);
+    float* const minmax = const_cast<float*>(t.block_minmax);
+    double* const bounds = const_cast<double*>(t.block_bounds);
+    for (uint32_t run = blockIdx.x * 4 + wave; run < n_runs; run += gridDim.x * 4) {
+        const uint32_t by = run / runs_per_row, bx0 = (run - by * runs_per_row) * kTblBlocks;
+        const uint32_t nb = min(kTblBlocks, bx_count - bx0);       // blocks of this run
+        const uint32_t c0 = bx0 * kBCX, y0 = by * kBCY;
+        const uint32_t ncols = min(nb * kBCX + 1, w - c0), nrows = min(kVY, h - y0);
+        // ---- column minima / maxima
+        float mn[4], mx[4];
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        mn = fminf(mn, __shfl_xor(mn, off));
-        mx = fmaxf(mx, __shfl_xor(mx, off));
-    }
-    float* minmax = const_cast<float*>(t.block_minmax);
-    if (threadIdx.x == 0) {
-        minmax[2 * blk] = mn;
-        minmax[2 * blk + 1] = mx;
-        // the view-independent half of the cull, in f64: bounding sphere of the block's patch and its corner directions
-        const double x0 = (double)(bx * kBCX), y0 = (double)(by * kBCY);
-        double x1 = x0 + (double)kBCX, y1 = y0 + (double)kBCY;
-        if (x1 > (double)(w - 1)) x1 = (double)(w - 1);
-        if (y1 > (double)(h - 1)) y1 = (double)(h - 1);
-        const double hmin = (double)mn, hmax = (double)mx, hmid = 0.5 * (hmin + hmax);
+        for (int k = 0; k < 4; ++k) { mn[k] = INFINITY; mx[k] = -INFINITY; }
+        for (uint32_t r = 0; r < nrows; ++r) {
+            const auto row = heights + (size_t)(y0 + r) * w + c0;
+            float v[4];
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k) {
+                const uint32_t c = lane + 64 * k;
+                v[k] = row[c < ncols ? c : ncols - 1];      // (unconditional loads; the surplus lanes re-read the last column)
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { mn[k] = fminf(mn[k], v[k]); mx[k] = fmaxf(mx[k], v[k]); }
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) { s_mn[wave][lane + 64 * k] = mn[k]; s_mx[wave][lane + 64 * k] = mx[k]; }
+        // ---- the f64 sin/cos pairs: lanes 0..2 latitudes (y0, y1, centre), lanes 3 + 3 b .. 5 + 3 b longitudes (x0, x1, centre) of block b
         const double D2R = 0.017453292519943295;
-        auto lon_of = [&](double vx) { return ((vx - (double)t.raster_x) * (double)t.scale_x + (double)t.model_x) * D2R; };
-        auto lat_of = [&](double vy) { return ((vy - (double)t.raster_y) * -(double)t.scale_y + (double)t.model_y) * D2R; };
-        const SinCos64 lo[2] = {sincos64(lon_of(x0)), sincos64(lon_of(x1))}, la[2] = {sincos64(lat_of(y0)), sincos64(lat_of(y1))};
-        const SinCos64 loc = sincos64(lon_of(0.5 * (x0 + x1))), lac = sincos64(lat_of(0.5 * (y0 + y1)));
-        double* bs = const_cast<double*>(t.block_bounds) + (size_t)blk * 4;                              // sphere
-        double* bb = const_cast<double*>(t.block_bounds) + (size_t)gridDim.x * 4 + (size_t)blk * 12;       // corner directions
-        double u[4][3];
-        for (int k = 0; k < 4; ++k) {
-            const SinCos64 &o = lo[k & 1], &a = la[k >> 1];
-            u[k][0] = a.c * o.c; u[k][1] = a.c * o.s; u[k][2] = a.s;
-            bb[3 * k] = u[k][0]; bb[3 * k + 1] = u[k][1]; bb[3 * k + 2] = u[k][2];
+        const double yy0 = (double)(by * kBCY);
+        double yy1 = yy0 + (double)kBCY;
+        if (yy1 > (double)(h - 1)) yy1 = (double)(h - 1);
+        if (lane < 3u + 3u * nb) {
+            double a;
+            if (lane < 3u) {
+                const double vy = lane == 0 ? yy0 : (lane == 1 ? yy1 : 0.5 * (yy0 + yy1));
+                a = ((vy - (double)t.raster_y) * -(double)t.scale_y + (double)t.model_y) * D2R;
+            } else {
+                const uint32_t b = (lane - 3u) / 3u, which = (lane - 3u) - 3u * b;
+                const double xx0 = (double)((bx0 + b) * kBCX);
+                double xx1 = xx0 + (double)kBCX;
+                if (xx1 > (double)(w - 1)) xx1 = (double)(w - 1);
+                const double vx = which == 0 ? xx0 : (which == 1 ? xx1 : 0.5 * (xx0 + xx1));
+                a = ((vx - (double)t.raster_x) * (double)t.scale_x + (double)t.model_x) * D2R;
+            }
+            const SinCos64 sc = sincos64(a);
+            s_sc[wave][lane][0] = sc.s;
+            s_sc[wave][lane][1] = sc.c;
         }
-        const double Rm = (double)kR0 + hmid;
-        const double c[3] = {Rm * lac.c * loc.c, Rm * lac.c * loc.s, Rm * lac.s};
-        double r2 = 0.0;
-        for (int k = 0; k < 4; ++k) {
-            const double dx = Rm * u[k][0] - c[0], dy = Rm * u[k][1] - c[1], dz = Rm * u[k][2] - c[2];
-            const double d2 = dx * dx + dy * dy + dz * dz;
-            r2 = d2 > r2 ? d2 : r2;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // (wave-private LDS: orders the compiler, emits nothing)
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- the blocks' own 61-column ranges
+        float bmn = INFINITY, bmx = -INFINITY;     // lane b ends up with block b's
+        for (uint32_t b = 0; b < nb; ++b) {
+            const uint32_t c = b * kBCX + lane;
+            float lo = lane < kVX && c < ncols ? s_mn[wave][c] : INFINITY, hi = lane < kVX && c < ncols ? s_mx[wave][c] : -INFINITY;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                lo = fminf(lo, __shfl_xor(lo, off));
+                hi = fmaxf(hi, __shfl_xor(hi, off));
+            }
+            if (lane == b) { bmn = lo; bmx = hi; }
         }
-        // every direction of the patch lies within the angular distance of the farthest corner from the centre direction,
-        // so the corners' chord distance bounds the sphere; + half the height range + margin
-        bs[0] = c[0]; bs[1] = c[1]; bs[2] = c[2];
-        bs[3] = sqrt(r2) + 0.5 * (hmax - hmin) + 8.0 + 64.0;
-        // How far the curved patch can stick out of the flat-faced hull of its eight slab corners (radially over the top
-        // face, sideways over the face along its equator-side parallel): at most the sagitta of the farthest corner's
-        // arc, R (1 - cos theta_max).  0.3 .. 0.7 m for a 60 x 15 cell block of a 1200-px tile, hundreds of metres for the
-        // blocks of a coarse tile: the occlusion filter pads its slab by this and only takes blocks where it is <= 1 m.
-        double dmin = 1.0;
-        const double uc[3] = {lac.c * loc.c, lac.c * loc.s, lac.s};
-        for (int k = 0; k < 4; ++k) {
-            const double d = u[k][0] * uc[0] + u[k][1] * uc[1] + u[k][2] * uc[2];
-            dmin = d < dmin ? d : dmin;
+        if (lane < nb) {
+            const uint32_t blk = by * bx_count + bx0 + lane;
+            minmax[2 * blk] = bmn;
+            minmax[2 * blk + 1] = bmx;
+            // the view-independent half of the cull, in f64: bounding sphere of the block's patch and its corner directions
+            const double hmin = (double)bmn, hmax = (double)bmx, hmid = 0.5 * (hmin + hmax);
+            const double(*sc)[2] = s_sc[wave];
+            const SinCos64 lo[2] = {{sc[3 + 3 * lane][0], sc[3 + 3 * lane][1]}, {sc[4 + 3 * lane][0], sc[4 + 3 * lane][1]}};
+            const SinCos64 la[2] = {{sc[0][0], sc[0][1]}, {sc[1][0], sc[1][1]}};
+            const SinCos64 loc = {sc[5 + 3 * lane][0], sc[5 + 3 * lane][1]}, lac = {sc[2][0], sc[2][1]};
+            double* bs = bounds + (size_t)blk * 4;                                              // sphere
+            double* bb = bounds + (size_t)blocks_per_tile * 4 + (size_t)blk * 12;               // corner directions
+            double u[4][3];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const SinCos64 &o = lo[k & 1], &a = la[k >> 1];
+                u[k][0] = a.c * o.c; u[k][1] = a.c * o.s; u[k][2] = a.s;
+                bb[3 * k] = u[k][0]; bb[3 * k + 1] = u[k][1]; bb[3 * k + 2] = u[k][2];
+            }
+            const double Rm = (double)kR0 + hmid;
+            const double c[3] = {Rm * lac.c * loc.c, Rm * lac.c * loc.s, Rm * lac.s};
+            double r2 = 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const double dx = Rm * u[k][0] - c[0], dy = Rm * u[k][1] - c[1], dz = Rm * u[k][2] - c[2];
+                const double d2 = dx * dx + dy * dy + dz * dz;
+                r2 = d2 > r2 ? d2 : r2;
+            }
+            // every direction of the patch lies within the angular distance of the farthest corner from the centre direction,
+            // so the corners' chord distance bounds the sphere; + half the height range + margin
+            bs[0] = c[0]; bs[1] = c[1]; bs[2] = c[2];
+            bs[3] = sqrt(r2) + 0.5 * (hmax - hmin) + 8.0 + 64.0;
+            // How far the curved patch can stick out of the flat-faced hull of its eight slab corners (radially over the top
+            // face, sideways over the face along its equator-side parallel): at most the sagitta of the farthest corner's
+            // arc, R (1 - cos theta_max).  0.3 .. 0.7 m for a 60 x 15 cell block of a 1200-px tile, hundreds of metres for the
+            // blocks of a coarse tile: the occlusion filter pads its slab by this and only takes blocks where it is <= 1 m.
+            double dmin = 1.0;
+            const double uc[3] = {lac.c * loc.c, lac.c * loc.s, lac.s};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const double d = u[k][0] * uc[0] + u[k][1] * uc[1] + u[k][2] * uc[2];
+                dmin = d < dmin ? d : dmin;
+            }
+            bounds[(size_t)blocks_per_tile * 16 + blk] = ((double)kR0 + (hmax > 0.0 ? hmax : 0.0) + 2.0) * (1.0 - dmin);
         }
-        const_cast<double*>(t.block_bounds)[(size_t)gridDim.x * 16 + blk] = ((double)kR0 + (hmax > 0.0 ? hmax : 0.0) + 2.0) * (1.0 - dmin);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // (the next run rewrites the strips)
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    for (uint32_t e = blk * 64 + threadIdx.x; e < w + h; e += gridDim.x * 64) {
+    for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < w + h; e += gridDim.x * 256) {
         float sn, cs;
         if (e < w) {
             sincos_f(vertex_lon(t, e), sn, cs);
@@ -968,10 +1032,17 @@ __global__ __launch_bounds__(256) void k_raster_big(FrameParams P) {
 // pixel's arithmetic (three vs_main, the perspective divides, the doubled area: resolve_setup) depends on the winning
 // triangle alone.  Each wave therefore lists the distinct winners of its 256 pixels -- a lane starts a new entry when
 // its id differs from its left neighbour's -- and computes their records densely, one triangle per lane, into a
-// per-wave LDS table; the pixels then finish from the record (resolve_pixel: the same operations on the same values as
-// the one-step resolve_varyings, bit for bit).  The table holds 32 records (at c4 a wave's 256 pixels share 6.7 winners
-// on average); a wave that meets more takes its rows in groups that fit, and a single row with more than that (far
-// field: a triangle or less per pixel) is shaded in one step per pixel.
+// per-wave LDS table; the pixels then finish from the record (resolve_pixel: the values of the one-step resolve_varyings,
+// bit for bit).  The table holds 32 records (at c4 a wave's 256 pixels share 6.7 winners on average); a wave that meets
+// more takes its rows in groups that fit, and a single row with more than that (far field: a triangle or less per
+// pixel) is shaded in one step per pixel.
+//
+// Round 3: the kernel is bound by instruction issue (vector AND scalar instructions take the SIMD's one issue slot), so
+// the row loop carries no per-row selects any more: what a row needs of the listing pass -- each pixel's record slot, or
+// its winner id where the row is shaded in one step -- waits in LDS (s_id, s_slot), the output pointers advance by the pitch,
+// the colour format is a template parameter, a record's kind-specific part is affine in the pixel (TriRecord), the
+// positions of the ring entries are lane constants, and a row none of whose pixels can have a non-zero contour factor
+// (decided by one comparison per pixel that can only err towards the long route) skips the post pass's divisions.
 constexpr int kRPW = 4;                            // pixel rows per wave
 constexpr int kResolveRows = 4 * kRPW;
 static_assert(kResolveRows == (int)kResolveBlockH && kResolveBlockW == 64u, "the host sizes k_resolve's block grid from these");
@@ -983,12 +1054,10 @@ constexpr uint32_t kRecCap = TOPO_RESOLVE_RECS;    // triangle records per wave
 #define TOPO_RESOLVE_WGS 4
 #endif
 static_assert(kRPW == 4, "Row4 below names the four rows of a wave");
-// One value per row of a wave.  Named members, not an array: `r == k ? a[k] : v` over an array is folded by the compiler
-// into a load from a run-time-indexed address, which sends the whole array to scratch memory.
+// One value per row of a wave.  Named members, not an array: an array indexed by a loop variable goes to scratch memory.
 template <typename T>
 struct Row4 {
     T a, b, c, d;
-    __device__ __forceinline__ T pick(int32_t r) const { return r == 0 ? a : r == 1 ? b : r == 2 ? c : d; }      // wave-uniform r
 };
 #define TOPO_ROWS4(X) X(0, a) X(1, b) X(2, c) X(3, d)
 
@@ -1016,57 +1085,58 @@ __device__ __forceinline__ bool resolve_strip_marked(const FrameParams& P, const
     const bool mark = TOPO_CHK(P.counters, at < (((size_t)P.n_views * P.W * P.H + 63) >> 6), 12u, at) ? P.dirty[at] != 0 : false;
     return seg <= last && mark;
 }
-// What a lane holds of a strip: the keys of its own four pixels and up to three depths of the ring around the strip
-// (entry e = lane + 64 k of: row -1 (66 entries), row 4 (66), columns -1 and 64 of rows 0..3 (8)).
+// What a lane holds of a strip: the keys of its own four pixels and up to three depths of the ring around the strip:
+// ring0 = the pixel above the lane's column (row -1), ring1 = the pixel below it (row 4), ring2 (lanes 0..11) = columns -1
+// and 64 of rows -1 .. 4 (lane = 2 (row + 1) + side).
 struct ResolveKeys {
     Row4<uint32_t> id, raw;
     uint32_t ring0, ring1, ring2;
 };
-constexpr uint32_t kRingEntries = 2 * 66 + 2 * kRPW;
-__device__ __forceinline__ void resolve_ring_pos(uint32_t e, int32_t& ly, int32_t& lx) {      // tile position (row 0..5, column 0..65) of ring entry e
-    if (e < 66u) { ly = 0; lx = (int32_t)e; }
-    else if (e < 132u) { ly = kRPW + 1; lx = (int32_t)e - 66; }
-    else { const int32_t k = (int32_t)(e < kRingEntries ? e : kRingEntries - 1u) - 132; ly = 1 + (k >> 1); lx = (k & 1) ? 65 : 0; }
-}
+constexpr uint32_t kRing2Lanes = 2 * (kRPW + 2);
 __device__ __forceinline__ void resolve_load_keys(const FrameParams& P, const ResolveBlock& B, uint32_t lane, uint32_t wave, ResolveKeys& K) {
     const uint64_t* vis = P.vis + (size_t)B.view * P.W * P.H;
     const int32_t px = B.bx + (int32_t)lane, sy = B.by + kRPW * (int32_t)wave;
-    // (outside the target the positions clamp to the edge; those lanes / rows only feed the contour taps' LDS tile)
+    // (outside the target the positions clamp to the edge -- the depth sampler is clamp-to-edge (texture.rs:113-117) --; lanes /
+    // rows beyond the target only feed the contour taps' LDS tile)
     const int32_t cx = px > P.W - 1 ? P.W - 1 : px;
-#define TOPO_X(r, m)                                                                  \
-    {                                                                                 \
-        const int32_t py = sy + r;                                                    \
-        const uint64_t key = vis[(size_t)(py > P.H - 1 ? P.H - 1 : py) * P.W + cx];   \
-        K.id.m = (uint32_t)key;                                                       \
-        K.raw.m = (uint32_t)(key >> 32);                                              \
+    const int32_t ym = sy > 0 ? sy - 1 : 0;            // the row above the strip
+    auto row_of = [&](int32_t y) { return y > P.H - 1 ? P.H - 1 : y; };      // (wave-uniform)
+    const uint64_t* col = vis + cx;
+#define TOPO_X(r, m)                                                      \
+    {                                                                     \
+        const uint64_t key = col[(size_t)row_of(sy + r) * P.W];           \
+        K.id.m = (uint32_t)key;                                           \
+        K.raw.m = (uint32_t)(key >> 32);                                  \
     }
     TOPO_ROWS4(TOPO_X)
 #undef TOPO_X
     // the ring: depth words only; every lane loads three (clamped positions: no branches around the loads)
-#define TOPO_RING(k, m)                                                                        \
-    {                                                                                          \
-        int32_t ly, lx;                                                                        \
-        resolve_ring_pos(lane + 64u * k, ly, lx);                                              \
-        int32_t x = B.bx + lx - 1, y = sy + ly - 1;                                            \
-        x = x < 0 ? 0 : (x > P.W - 1 ? P.W - 1 : x);   /* clamp-to-edge depth sampler (texture.rs:113-117) */ \
-        y = y < 0 ? 0 : (y > P.H - 1 ? P.H - 1 : y);                                           \
-        K.m = reinterpret_cast<const uint32_t*>(vis + (size_t)y * P.W + x)[1];                 \
+    K.ring0 = reinterpret_cast<const uint32_t*>(col + (size_t)ym * P.W)[1];
+    K.ring1 = reinterpret_cast<const uint32_t*>(col + (size_t)row_of(sy + kRPW) * P.W)[1];
+    {
+        const int32_t e = (int32_t)(lane < kRing2Lanes ? lane : kRing2Lanes - 1u);
+        int32_t x = (e & 1) ? B.bx + 64 : B.bx - 1, y = sy + (e >> 1) - 1;
+        x = x < 0 ? 0 : (x > P.W - 1 ? P.W - 1 : x);
+        y = y < 0 ? 0 : (y > P.H - 1 ? P.H - 1 : y);
+        K.ring2 = reinterpret_cast<const uint32_t*>(vis + (size_t)y * P.W + x)[1];
     }
-    TOPO_RING(0u, ring0)
-    TOPO_RING(1u, ring1)
-    TOPO_RING(2u, ring2)
-#undef TOPO_RING
 }
 
+template <bool kBgra>
+__device__ __forceinline__ uint32_t surface_order(uint32_t c) {      // Rgba -> the surface's channel order
+    return kBgra ? (c & 0xFF00FF00u) | ((c >> 16) & 0xFFu) | ((c & 0xFFu) << 16) : c;
+}
+template <bool kBgra>
 __device__ __forceinline__ void resolve_fill_sky(const FrameParams& P, const OutputParams& O, const ResolveBlock& B, uint32_t lane, uint32_t wave) {
     const int32_t px = B.bx + (int32_t)lane;
     if (px >= P.W) return;
-    uint8_t* const rgba_col = O.rgba + (size_t)B.view * O.rgba_view_stride + (size_t)px * 4;
-    uint8_t* const depth_col = O.depth ? reinterpret_cast<uint8_t*>(O.depth) + (size_t)B.view * O.depth_view_stride + (size_t)px * 4 : nullptr;
-    const uint32_t sky = P.bgra ? (P.sky_c8 & 0xFF00FF00u) | ((P.sky_c8 >> 16) & 0xFFu) | ((P.sky_c8 & 0xFFu) << 16) : P.sky_c8;
-    for (int32_t ty = kRPW * (int32_t)wave; ty < kRPW * ((int32_t)wave + 1) && B.by + ty < P.H; ++ty) {
-        *reinterpret_cast<uint32_t*>(rgba_col + (size_t)(B.by + ty) * O.rgba_pitch) = sky;
-        if (depth_col) *reinterpret_cast<float*>(depth_col + (size_t)(B.by + ty) * O.depth_pitch) = 1.0f;
+    const int32_t y0 = B.by + kRPW * (int32_t)wave;
+    uint8_t* rgba = O.rgba + (size_t)B.view * O.rgba_view_stride + (size_t)y0 * O.rgba_pitch + (size_t)px * 4;
+    uint8_t* depth = O.depth ? reinterpret_cast<uint8_t*>(O.depth) + (size_t)B.view * O.depth_view_stride + (size_t)y0 * O.depth_pitch + (size_t)px * 4 : nullptr;
+    const uint32_t sky = surface_order<kBgra>(P.sky_c8);
+    for (int32_t r = 0; r < kRPW && y0 + r < P.H; ++r, rgba += O.rgba_pitch) {
+        *reinterpret_cast<uint32_t*>(rgba) = sky;
+        if (depth) { *reinterpret_cast<float*>(depth) = 1.0f; depth += O.depth_pitch; }
     }
 }
 __device__ __forceinline__ uint32_t pop_bit(uint64_t& m) {      // wave-uniform mask: scalar instructions
@@ -1074,11 +1144,22 @@ __device__ __forceinline__ uint32_t pop_bit(uint64_t& m) {      // wave-uniform 
     m &= m - 1ull;
     return j;
 }
+// A wave's LDS tables are written and read by that wave alone, and a wave's LDS operations complete in order; what the
+// hardware does not promise is that the COMPILER keeps a lane's read behind another lane's write to a different address.
+// This fence (no instruction: it only orders the compiler's memory operations within the wave) stands between every write
+// phase and the read phase that follows it.
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // The four waves of a workgroup share the tables and the list of 64 x 16 blocks, and nothing else: wave w takes rows
 // 4w .. 4w+3 of every block (a 64 x 4 strip) with its own halo, its own depth tile and its own record table, at its own pace --
 // no barrier after the tables are in place.  (With one depth tile per block, two barriers per block made every wave wait for the
 // block's slowest: 29 % of all wave time.)
+// kSrgb: the targets are *Srgb formats (encode on store, decode on sample); otherwise plain unorm8.  kBgra: channel order.
+template <bool kSrgb, bool kBgra>
 __global__ __launch_bounds__(256, TOPO_RESOLVE_WGS) void k_resolve(FrameParams P, OutputParams O) {
     __shared__ float s_thresh[258];    // sRGB code boundaries; [255..257] = NaN: never <= anything (srgb_encode_lut probes up to 256)
     __shared__ float s_decode[256];
@@ -1087,6 +1168,8 @@ __global__ __launch_bounds__(256, TOPO_RESOLVE_WGS) void k_resolve(FrameParams P
     __shared__ float s_lin[4][kRPW + 2][66];                 // per wave: linear depth of the strip + halo
     __shared__ uint32_t s_rec[4][kTriRecordWords][kRecCap];  // per wave: the records, word-major (lanes with consecutive slots hit consecutive banks)
     __shared__ uint32_t s_uid[4][kRecCap];                   // per wave: the distinct winner ids
+    __shared__ uint32_t s_id[4][kRPW][64];                   // per wave and pixel: the winner id ...
+    __shared__ uint16_t s_slot[4][kRPW][64];                 // ... and the number of its entry among the strip's table entries (0xFFFF: no winner)
     const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int32_t tx = (int32_t)lane;
     // Blocks are dealt out with a static stride: workgroup g takes blocks g, g + grid, g + 2 grid, ... -- a sample of every
@@ -1112,7 +1195,14 @@ __global__ __launch_bounds__(256, TOPO_RESOLVE_WGS) void k_resolve(FrameParams P
 #define TOPO_PROF(slot)
 #endif
     float (*const lin_tile)[66] = s_lin[wave];
+    uint32_t (*const id_tile)[64] = s_id[wave];
+    uint16_t (*const slot_tile)[64] = s_slot[wave];
     const int32_t sy0 = kRPW * (int32_t)wave;      // the strip's first row within its block
+    // lane constants: the pixel's column as a double (TriRecord kind 1), the lane's entry of the ring's side columns
+    const double lane_d = (double)tx;
+    const float two_over_w = div_f(2.0f, (float)P.W), two_over_h = div_f(2.0f, (float)P.H);
+    const int32_t ring2_e = (int32_t)(lane < kRing2Lanes ? lane : kRing2Lanes - 1u);
+    float* const ring2_at = &lin_tile[ring2_e >> 1][(ring2_e & 1) ? 65 : 0];
 
     for (uint32_t j0 = 0; j0 < per_wg; j0 += 64) {
         const uint32_t nj = per_wg - j0 < 64u ? per_wg - j0 : 64u;
@@ -1140,43 +1230,39 @@ __global__ __launch_bounds__(256, TOPO_RESOLVE_WGS) void k_resolve(FrameParams P
             ResolveKeys Kn;
             const uint32_t j_cur = j_next;
             if (mm) { j_next = pop_bit(mm); resolve_load_keys(P, block_of(j_next), lane, wave, Kn); }      // in flight while strip i is shaded
-            for (uint32_t f = 0; f < fills_per_iter && mc; ++f) resolve_fill_sky(P, O, block_of(pop_bit(mc)), lane, wave);
+            for (uint32_t f = 0; f < fills_per_iter && mc; ++f) resolve_fill_sky<kBgra>(P, O, block_of(pop_bit(mc)), lane, wave);
             TOPO_PROF(1)  // issue of the next keys + sky fills
             if (i >= n_marked) break;
             const ResolveBlock B = block_of(j_cur);
-            const int32_t px = B.bx + tx;
+            const int32_t px = B.bx + tx, y0 = B.by + sy0;
             const bool in_x = px < P.W;        // lanes beyond the target's right edge stay: they compute triangle records
-            uint8_t* const rgba_col = O.rgba + (size_t)B.view * O.rgba_view_stride + (size_t)px * 4;
-            uint8_t* const depth_col = O.depth ? reinterpret_cast<uint8_t*>(O.depth) + (size_t)B.view * O.depth_view_stride + (size_t)px * 4 : nullptr;
-            const Row4<uint32_t> ids = K.id, raws = K.raw;
-            const bool terrain = raws.a != 0x3F800000u || raws.b != 0x3F800000u || raws.c != 0x3F800000u || raws.d != 0x3F800000u ||
-                                 K.ring0 != 0x3F800000u || K.ring1 != 0x3F800000u || (lane + 128u < kRingEntries && K.ring2 != 0x3F800000u);
+            const int32_t n_rows = P.H - y0 < kRPW ? P.H - y0 : kRPW;      // rows of the strip inside the target (>= 1)
+            const bool terrain = K.raw.a != 0x3F800000u || K.raw.b != 0x3F800000u || K.raw.c != 0x3F800000u || K.raw.d != 0x3F800000u ||
+                                 K.ring0 != 0x3F800000u || K.ring1 != 0x3F800000u || (lane < kRing2Lanes && K.ring2 != 0x3F800000u);
             TOPO_PROF(2)  // wait for this strip's keys
-            // (the tile is written and read by this wave alone: the LDS operations of one wave complete in order)
-#define TOPO_X(r, m) lin_tile[r + 1][tx + 1] = linear_depth(bits_f(raws.m));
-            TOPO_ROWS4(TOPO_X)
-#undef TOPO_X
-            {
-                int32_t ly, lx;
-                resolve_ring_pos(lane, ly, lx);
-                lin_tile[ly][lx] = linear_depth(bits_f(K.ring0));
-                resolve_ring_pos(lane + 64u, ly, lx);
-                lin_tile[ly][lx] = linear_depth(bits_f(K.ring1));
-                resolve_ring_pos(lane + 128u, ly, lx);
-                if (lane + 128u < kRingEntries) lin_tile[ly][lx] = linear_depth(bits_f(K.ring2));
-            }
-            const bool any_terrain = __ballot(terrain) != 0ull;
-            TOPO_PROF(4)  // linear depths
-            // the depth output is the key's depth word: stored now, so that the four words are not held through the shading
-            if (any_terrain && in_x && depth_col) {
-#define TOPO_X(r, m) if (B.by + sy0 + r < P.H) *reinterpret_cast<uint32_t*>(depth_col + (size_t)(B.by + sy0 + r) * O.depth_pitch) = raws.m;
-                TOPO_ROWS4(TOPO_X)
-#undef TOPO_X
-            }
-            if (!any_terrain) {                // marked, but every key still cleared (a mark covers 64 keys): the cleared texel and depth 1
-                resolve_fill_sky(P, O, B, lane, wave);
+            if (__ballot(terrain) == 0ull) {   // marked, but every key still cleared (a mark covers 64 keys): the cleared texel and depth 1
+                resolve_fill_sky<kBgra>(P, O, B, lane, wave);
                 K = Kn;
                 continue;
+            }
+            wave_lds_fence();                  // (the previous strip's reads of the tiles are done)
+#define TOPO_X(r, m) lin_tile[r + 1][tx + 1] = linear_depth(bits_f(K.raw.m));
+            TOPO_ROWS4(TOPO_X)
+#undef TOPO_X
+            lin_tile[0][tx + 1] = linear_depth(bits_f(K.ring0));
+            lin_tile[kRPW + 1][tx + 1] = linear_depth(bits_f(K.ring1));
+            {
+                const float l2 = linear_depth(bits_f(K.ring2));
+                if (lane < kRing2Lanes) *ring2_at = l2;
+            }
+            TOPO_PROF(4)  // linear depths
+            uint8_t* rgba_p = O.rgba + (size_t)B.view * O.rgba_view_stride + (size_t)y0 * O.rgba_pitch + (size_t)px * 4;
+            // the depth output is the key's depth word: stored now, so that the four words are not held through the shading
+            if (in_x && O.depth) {
+                uint8_t* dp = reinterpret_cast<uint8_t*>(O.depth) + (size_t)B.view * O.depth_view_stride + (size_t)y0 * O.depth_pitch + (size_t)px * 4;
+#define TOPO_X(r, m) if (r < n_rows) { *reinterpret_cast<uint32_t*>(dp) = K.raw.m; dp += O.depth_pitch; }
+                TOPO_ROWS4(TOPO_X)
+#undef TOPO_X
             }
             const ViewDev& view = P.views[B.view];
             // what fs_main reads of the view, once per strip and wave-uniform: left to the compiler these are re-loaded in every
@@ -1186,80 +1272,94 @@ __global__ __launch_bounds__(256, TOPO_RESOLVE_WGS) void k_resolve(FrameParams P
             const float cam_x = unif(view.cam_x), cam_y = unif(view.cam_y);
             const int32_t view_mode = uni(view.view_mode);
             // ---- the distinct winners of this wave's pixels: a lane opens an entry where its id differs from its left
-            // neighbour's.  slot[r] = the entry of the lane's pixel in row r, counted over the whole wave; n_row[r] = entries of row r.
-            Row4<uint32_t> slot, n_row;
-            uint32_t leaders = 0;              // bit r: this lane opens an entry in row r
+            // neighbour's.  Entries are numbered over the strip's rows that fit the table; n_row = entries of a row.  What the
+            // row loop needs of a pixel waits in LDS: its winner id and its entry number.
+            Row4<uint32_t> n_row;
+            uint32_t n_all = 0;
             {
-                uint32_t n = 0;
-#define TOPO_X(r, m)                                                                                                                   \
-    {                                                                                                                                  \
-        const bool valid = in_x && B.by + sy0 + r < P.H && ids.m != kNoTri;                                                            \
-        const uint32_t left = (uint32_t)__shfl_up((int)ids.m, 1);                                                                      \
-        const bool leader = valid && (lane == 0 || ids.m != left);                                                                     \
-        const uint64_t mask = __ballot(leader);                                                                                        \
-        slot.m = n + (uint32_t)__popcll(mask & ((2ull << lane) - 1ull)) - 1u; /* valid lanes: the last leader at or before them */      \
-        leaders |= leader ? (1u << r) : 0u;                                                                                            \
-        n_row.m = (uint32_t)__popcll(mask);                                                                                            \
-        n += n_row.m;                                                                                                                  \
+#define TOPO_X(r, m)                                                                                                            \
+    {                                                                                                                           \
+        const bool valid = in_x && r < n_rows && K.id.m != kNoTri;                                                              \
+        const uint32_t left = (uint32_t)__shfl_up((int)K.id.m, 1);                                                              \
+        const bool leader = valid && (lane == 0 || K.id.m != left);                                                             \
+        const uint64_t mask = __ballot(leader);                                                                                 \
+        n_row.m = (uint32_t)__popcll(mask);                                                                                     \
+        const uint32_t slot = n_all + (uint32_t)__popcll(mask & ((2ull << lane) - 1ull)) - 1u; /* valid lanes: the last leader at or before them */ \
+        id_tile[r][tx] = valid ? K.id.m : kNoTri;                                                                               \
+        slot_tile[r][tx] = (uint16_t)(valid ? slot : 0xFFFFu);                                                                  \
+        if (leader && n_row.m <= kRecCap && slot < kRecCap) s_uid[wave][slot] = K.id.m; /* the first group's ids (later groups: below) */ \
+        n_all += n_row.m <= kRecCap ? n_row.m : 0u;                                                                             \
     }
                 TOPO_ROWS4(TOPO_X)
 #undef TOPO_X
             }
+            wave_lds_fence();
 #ifdef TOPO_RESOLVE_STATS      // experiment build: how well do winners share?  counters[12] entries, [13] waves with terrain, [14] groups, [15] terrain pixels
             {
-                uint32_t n_all = 0, npx = 0;
-#define TOPO_X(r, m) n_all += n_row.m; npx += (uint32_t)__popcll(__ballot(in_x && ids.m != kNoTri));
+                uint32_t npx = 0;
+#define TOPO_X(r, m) npx += (uint32_t)__popcll(__ballot(in_x && K.id.m != kNoTri));
                 TOPO_ROWS4(TOPO_X)
 #undef TOPO_X
                 if (lane == 0 && n_all) { atomicAdd(&P.counters[12], n_all); atomicAdd(&P.counters[13], 1u); atomicAdd(&P.counters[15], npx); }
             }
 #endif
-            // Rows are taken in groups of consecutive rows whose entries fit the table.  Near field: all four rows in one
-            // group, a handful of records.
+            const float gx = pixel_gx(px, two_over_w);
+            // Rows are taken in groups of consecutive rows whose table entries fit the table (near field: all four rows in one
+            // group, a handful of records); a row with more entries than the table holds is a group of its own, shaded in
+            // one step per pixel (resolve_varyings), as every row was in round 1.
             int32_t r0 = 0;
-            uint32_t gbase = 0;
+            uint32_t gbase = 0;            // table entries of the groups before this one
+            const bool one_group = n_all <= kRecCap && n_row.a <= kRecCap && n_row.b <= kRecCap && n_row.c <= kRecCap && n_row.d <= kRecCap;
 #pragma unroll 1
-            while (r0 < kRPW) {
-                int32_t r1 = r0;
-                uint32_t cnt = 0;
-#define TOPO_X(r, m) if (r >= r0 && r == r1 && cnt + n_row.m <= kRecCap) { cnt += n_row.m; r1 = r + 1; }
-                TOPO_ROWS4(TOPO_X)
+            while (r0 < n_rows) {
+                int32_t r1;
+                uint32_t cnt;
+                bool table = true;
+                if (one_group) {
+                    r1 = n_rows;
+                    cnt = n_all;
+                } else {
+                    r1 = r0;
+                    cnt = 0;
+#define TOPO_X(r, m) if (r >= r0 && r == r1 && n_row.m <= kRecCap && cnt + n_row.m <= kRecCap) { cnt += n_row.m; r1 = r + 1; }
+                    TOPO_ROWS4(TOPO_X)
 #undef TOPO_X
-                // a single row with more distinct winners than the table holds (far field, a triangle per pixel): that row is
-                // shaded pixel by pixel in one step (resolve_varyings), as every row was in round 1
-                const bool table = r1 > r0;
-                if (!table) {
-                    r1 = r0 + 1;
-                    cnt = n_row.pick(r0);
+                    if (r1 == r0) {            // the row at r0 alone exceeds the table
+                        table = false;
+                        r1 = r0 + 1;
+                    } else if (gbase != 0u) {
+                        // a later group: its ids were not listed above (their entry numbers lie beyond the table): listed now -- a
+                        // lane is the leader of its entry iff its left neighbour has another one
+                        for (int32_t r = r0; r < r1; ++r) {
+                            const uint32_t e = slot_tile[r][tx], el = (uint32_t)__shfl_up((int)e, 1);
+                            if (e != 0xFFFFu && (lane == 0 || e != el) && TOPO_CHK(P.counters, e - gbase < kRecCap, 15u, e)) s_uid[wave][e - gbase] = id_tile[r][tx];
+                        }
+                    }
                 }
 #ifdef TOPO_RESOLVE_STATS
                 if (lane == 0 && cnt) atomicAdd(&P.counters[14], 1u);
 #endif
-                // the group's winner ids, pushed by the lanes that opened the entries
-#define TOPO_X(r, m) if (table && r >= r0 && r < r1 && (leaders >> r & 1u)) s_uid[wave][slot.m - gbase] = ids.m;
-                TOPO_ROWS4(TOPO_X)
-#undef TOPO_X
-                if (table && lane < cnt) {      // one triangle per lane: everything that depends on the triangle alone
-                    const uint32_t id = s_uid[wave][lane];
-                    const uint32_t draw = id >> 1, fan = id & 1u;
-                    const uint32_t rank = fastdiv(draw, P.div_tris), tri = draw - rank * P.tris_per_tile;
-                    TriRecord rec;
-                    if (TOPO_CHK(P.counters, rank < P.n_tiles, 13u, id)) resolve_setup(P.tiles[rank], P.tile_w, P.div_hm1, P.tile_h - 1, view, P.W, P.H, tri, fan, s_ndec, rec);
-                    else rec = TriRecord{};
-                    int k = 0;
+                if (table && cnt) {            // one triangle per lane: everything that depends on the triangle alone
+                    wave_lds_fence();
+                    if (lane < cnt) {
+                        const uint32_t id = s_uid[wave][lane];
+                        const uint32_t draw = id >> 1, fan = id & 1u;
+                        const uint32_t rank = fastdiv(draw, P.div_tris), tri = draw - rank * P.tris_per_tile;
+                        TriRecord rec;
+                        if (TOPO_CHK(P.counters, rank < P.n_tiles, 13u, id)) resolve_setup(P.tiles[rank], P.tile_w, P.div_hm1, P.tile_h - 1, view, P.W, P.H, tri, fan, s_ndec, B.bx, y0, rec);
+                        else rec = TriRecord{};
+                        int k = 0;
 #define TOPO_X(f) s_rec[wave][k++][lane] = rec.f;
-                    TOPO_TRIREC_WORDS(TOPO_X)
+                        TOPO_TRIREC_WORDS(TOPO_X)
 #undef TOPO_X
+                    }
+                    wave_lds_fence();
                 }
                 TOPO_PROF(5)  // winners: entries, records (gathers)
-                // (the table is written and read by the same wave: the LDS operations of one wave complete in order)
 #pragma unroll 1
-                for (int32_t r = r0; r < r1; ++r) {
-                    const int32_t ty = sy0 + r, py = B.by + ty;
-                    if (py >= P.H) break;
-                    // (r is wave-uniform: pick() is scalar-conditioned moves)
-                    const uint32_t id_r = ids.pick(r), sl = slot.pick(r) - gbase;
-                    const uint32_t id = in_x ? id_r : kNoTri;
+                for (int32_t r = r0; r < r1; ++r, rgba_p += O.rgba_pitch) {
+                    const int32_t py = y0 + r;
+                    const uint32_t sel = table ? (uint32_t)slot_tile[r][tx] : id_tile[r][tx];      // the pixel's entry number / its winner id
                     // the contour taps first: they depend on nothing, so their LDS trip overlaps the record's
                     float ln[8];
                     {
@@ -1275,38 +1375,46 @@ __global__ __launch_bounds__(256, TOPO_RESOLVE_WGS) void k_resolve(FrameParams P
                     const float lin_c = lin_tile[r + 1][tx + 1];
                     // render target texel (Rgba8UnormSrgb): the cleared value or the shaded winner
                     uint32_t c8 = P.sky_c8;
-                    if (id != kNoTri) {
+                    if (sel != (table ? 0xFFFFu : kNoTri)) {
                         float lin[4] = {0.0f, 0.71f, 0.885f, 1.0f};
                         f3 wpos = {0.0f, 0.0f, 0.0f}, wnrm;
                         bool ok;
                         if (table) {
+                            const uint32_t sl = sel - gbase;
                             TriRecord rec;
                             int k = 0;
 #define TOPO_X(f) rec.f = s_rec[wave][k++][sl];
                             TOPO_TRIREC_WORDS(TOPO_X)
 #undef TOPO_X
-                            ok = resolve_pixel(rec, P.W, P.H, px, py, wpos.x, wpos.y, wnrm);
+                            const PixelAt at = {px, py, lane_d, (double)r, gx, pixel_gy(py, two_over_h)};
+                            ok = resolve_pixel(rec, at, wpos.x, wpos.y, wnrm);
                         } else {
-                            const uint32_t draw = id >> 1, fan = id & 1u;
+                            const uint32_t draw = sel >> 1, fan = sel & 1u;
                             const uint32_t rank = fastdiv(draw, P.div_tris), tri = draw - rank * P.tris_per_tile;
-                            ok = TOPO_CHK(P.counters, rank < P.n_tiles, 13u, id) &&
+                            ok = TOPO_CHK(P.counters, rank < P.n_tiles, 13u, sel) &&
                                  resolve_varyings(P.tiles[rank], P.tile_w, P.div_hm1, P.tile_h - 1, view, P.W, P.H, tri, fan, s_ndec, px, py, wpos, wnrm);
                         }
                         if (ok) shade_fragment(view_mode, sun, cam_x, cam_y, (float)px + 0.5f, (float)py + 0.5f, wpos, wnrm, lin);
-                        c8 = (P.linear_target ? to_unorm8(lin[0]) | (to_unorm8(lin[1]) << 8) | (to_unorm8(lin[2]) << 16)
-                                              : srgb_encode_lut3(s_thresh, lut, lin[0], lin[1], lin[2])) | (to_unorm8(lin[3]) << 24);
+                        c8 = (kSrgb ? srgb_encode_lut3(s_thresh, lut, lin[0], lin[1], lin[2]) : to_unorm8(lin[0]) | (to_unorm8(lin[1]) << 8) | (to_unorm8(lin[2]) << 16)) |
+                             (to_unorm8(lin[3]) << 24);
                     }
-                    uint32_t out = post_pixel_t<true>(s_thresh, s_decode, c8, lin_c, ln, lut, P.linear_target == 0u);
-                    if (P.bgra) out = (out & 0xFF00FF00u) | ((out >> 16) & 0xFFu) | ((out & 0xFFu) << 16);
-                    if (in_x) *reinterpret_cast<uint32_t*>(rgba_col + (size_t)py * O.rgba_pitch) = out;
+                    // The post pass.  Its contour factor a is 0 iff RN(contour / centre) <= 0.05f; contour <= 0.0499f * centre
+                    // (centre is a linear depth: 50 .. 5e5) puts the quotient below 0.04991: such a pixel returns its texel
+                    // unchanged, and a row of them skips the divisions.  (A NaN fails the comparison and takes the long route.)
+                    float contour = 8.0f * lin_c;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) contour -= ln[k];
+                    uint32_t out = c8;
+                    if (__ballot(!(contour <= 0.0499f * lin_c)) != 0ull) out = post_pixel_t<true>(s_thresh, s_decode, c8, lin_c, ln, lut, kSrgb);
+                    if (in_x) *reinterpret_cast<uint32_t*>(rgba_p) = surface_order<kBgra>(out);
                 }
                 TOPO_PROF(6)  // pixels
-                gbase += cnt;
+                gbase += table ? cnt : 0u;
                 r0 = r1;
             }
             K = Kn;
         }
-        while (mc) resolve_fill_sky(P, O, block_of(pop_bit(mc)), lane, wave);
+        while (mc) resolve_fill_sky<kBgra>(P, O, block_of(pop_bit(mc)), lane, wave);
         TOPO_PROF(1)
     }
 #ifdef TOPO_RESOLVE_PROF
@@ -1493,9 +1601,11 @@ __global__ void k_probe_div(int kind, const float* x, const float* y, float* out
 // launchers
 // ======================================================================================================
 
-void launch_block_minmax(const TileDev& tile, uint32_t w, uint32_t h, hipStream_t s) {
+void launch_block_tables(const TileDev* tiles, uint32_t first, uint32_t count, uint32_t w, uint32_t h, hipStream_t s) {
+    if (count == 0) return;
     const uint32_t bxc = (w - 1 + kBCX - 1) / kBCX, byc = (h - 1 + kBCY - 1) / kBCY;
-    hipLaunchKernelGGL(k_block_minmax, dim3(bxc * byc), dim3(64), 0, s, tile, w, h, bxc);
+    const uint32_t runs = (bxc + kTblBlocks - 1) / kTblBlocks * byc;
+    hipLaunchKernelGGL(k_block_tables, dim3((runs + 3) / 4, count), dim3(256), 0, s, tiles, first, w, h, bxc, byc);
 }
 
 void launch_normals_interior(const TileDev* tiles, uint32_t first, uint32_t count, uint32_t w, uint32_t h, int lds_rows,
@@ -1579,9 +1689,14 @@ void launch_resolve(const FrameParams& p, const OutputParams& o, hipStream_t s) 
     if (n_blocks == 0) return;
     // four times the resident workgroups: the hardware then hands out workgroups as others finish, which evens out what the
     // static stride leaves uneven (c3: 0.21 -> 0.16 ms; c4, with 128 blocks per resident workgroup, does not care)
-    unsigned resident = 4u * resident_grid<3>(k_resolve, 256 * TOPO_RESOLVE_WGS);
+    // (the four instantiations differ by a few instructions: one occupancy query serves them all)
+    unsigned resident = 4u * resident_grid<3>(k_resolve<true, false>, 256 * TOPO_RESOLVE_WGS);
     if (const char* e = getenv("TOPO_RESOLVE_GRID")) resident = (unsigned)atoi(e) ? (unsigned)atoi(e) : n_blocks;      // experiments: 0 = one block per workgroup
-    hipLaunchKernelGGL(k_resolve, dim3(n_blocks < resident ? n_blocks : resident), dim3(256), 0, s, p, o);
+    const dim3 grid(n_blocks < resident ? n_blocks : resident), block(256);
+    if (!p.linear_target && !p.bgra) hipLaunchKernelGGL((k_resolve<true, false>), grid, block, 0, s, p, o);
+    else if (!p.linear_target) hipLaunchKernelGGL((k_resolve<true, true>), grid, block, 0, s, p, o);
+    else if (!p.bgra) hipLaunchKernelGGL((k_resolve<false, false>), grid, block, 0, s, p, o);
+    else hipLaunchKernelGGL((k_resolve<false, true>), grid, block, 0, s, p, o);
 }
 
 void launch_overlay(const OverlayVertex* verts, const uint32_t* idx, uint32_t n_tris, uint32_t n_verts, float width, int32_t W, int32_t H, uint64_t* keys,

@@ -616,57 +616,111 @@ TOPO_HD bool resolve_varyings(const TileDev& t, uint32_t tile_w, FastDiv div_hm1
 // ---- the same varyings in two steps: once per winning triangle, then per pixel ---------------------------------------
 // Many pixels share a winner (the near field is made of triangles hundreds of pixels large), and two thirds of
 // resolve_varyings -- three vs_main, the perspective divides, the doubled area -- depend on the triangle alone.
-// resolve_setup() computes that part into a 26-word record; resolve_pixel() finishes a pixel from the record with the
-// SAME operations on the same values as resolve_varyings (so the two routes agree bit for bit:
-// tests/test_emul_cpu.py::test_split_resolve_equals_resolve_varyings, and k_resolve uses either route per wave).
-// The record is 26 plain 32-bit words with names (floats as their bit patterns) and no arrays or unions in it: the
-// compiler keeps such a struct in registers, whereas word-indexed access to a union ends up in scratch memory.
-//   kind 1 / 2 (uncut, int32 / int64 barycentrics): u0..u5 = X0 X1 X2 Y0 Y1 Y2 (snapped vertices, int32),
-//                                                    u6..u8 = 1 / w_k, u9 = 1 / |doubled area|
-//   kind 3 (primitive cut by the near plane):        u0..u8 = (clip.x, clip.y, clip.w) of vertices 0, 1, 2   (homogeneous_weights)
+// resolve_setup() computes that part into a 34-word record; resolve_pixel() finishes a pixel from the record and yields
+// the SAME values as resolve_varyings, bit for bit (tests/test_emul_cpu.py::test_split_resolve_equals_resolve_varyings;
+// k_resolve uses either route per row).  The record is plain 32-bit words with names (floats and the halves of doubles as
+// their bit patterns) and no arrays or unions in it: the compiler keeps such a struct in registers, whereas word-indexed
+// access to a union ends up in scratch memory.
+//
+//   kind 1 (uncut): the barycentric numerators are the exact integers F_i(p) = dy_i (cx - ax_i) - dx_i (cy - ay_i), an
+//     affine function of the pixel.  With |doubled area| < 2^52 every F_i of a covered pixel lies in [0, |area|], and
+//     relative to a reference pixel (ox, oy) at most 63 px / 15 rows away all terms stay below 2^53: binary64 holds them
+//     EXACTLY, so F_i = fma(A_i, px - ox, fma(B_i, py - oy, C_i)) with A_i = 256 dy_i, B_i = -256 dx_i, C_i = F_i(ox, oy) is
+//     the same integer the int32 / int64 forms of triangle_bary() give, and the f64 -> f32 conversion rounds it once,
+//     to nearest even, as the integer -> f32 conversion does.  Two fused multiply-adds and a conversion per numerator
+//     replace two multiplications, three subtractions and (beyond 64 px) a 12-instruction int64 -> f32 conversion; F_0
+//     comes from F_0 + F_1 + F_2 = |area|.   u0..u11 = A1 B1 C1 A2 B2 C2 (doubles, low word first), u12 u13 = |area|,
+//     iw0..2 = 1 / w_k, iA = 1 / |area|.
+//   kind 2 (uncut, |area| >= 2^52 or a reference value beyond 2^52 -- triangles tens of thousands of pixels across):
+//     u0..u5 = X0 X1 X2 Y0 Y1 Y2, the int64 form per pixel.
+//   kind 3 (primitive cut by the near plane): u0..u8 = the nine 2x2 determinants of homogeneous_weights() -- they depend
+//     on the primitive alone -- so that a weight is q_i = fma(u[3i], gx, fma(u[3i+1], gy, u[3i+2])).
 //   kind 0: no varyings (cannot happen for an id that won a pixel; the pixel then keeps the cleared colour)
 //   wx, wy: world position x, y of the three vertices (fs_main reads world_pos.xy only); n: world normals
-#define TOPO_TRIREC_WORDS(X)                                                                                      \
-    X(u0) X(u1) X(u2) X(u3) X(u4) X(u5) X(u6) X(u7) X(u8) X(u9) X(wx0) X(wx1) X(wx2) X(wy0) X(wy1) X(wy2) X(n0x) \
-    X(n0y) X(n0z) X(n1x) X(n1y) X(n1z) X(n2x) X(n2y) X(n2z) X(kind)
+#define TOPO_TRIREC_WORDS(X)                                                                                                   \
+    X(u0) X(u1) X(u2) X(u3) X(u4) X(u5) X(u6) X(u7) X(u8) X(u9) X(u10) X(u11) X(u12) X(u13) X(iw0) X(iw1) X(iw2) X(iA) X(wx0)  \
+    X(wx1) X(wx2) X(wy0) X(wy1) X(wy2) X(n0x) X(n0y) X(n0z) X(n1x) X(n1y) X(n1z) X(n2x) X(n2y) X(n2z) X(kind)
 struct TriRecord {
 #define TOPO_X(f) uint32_t f;
     TOPO_TRIREC_WORDS(TOPO_X)
 #undef TOPO_X
 };
-constexpr int kTriRecordWords = 26;
+constexpr int kTriRecordWords = 34;
 static_assert(sizeof(TriRecord) == kTriRecordWords * 4, "TriRecord is stored word by word");
 
+TOPO_HD double f64_from_words(uint32_t lo, uint32_t hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __hiloint2double((int)hi, (int)lo);
+#else
+    const uint64_t u = ((uint64_t)hi << 32) | lo;
+    double d;
+    memcpy(&d, &u, 8);
+    return d;
+#endif
+}
+TOPO_HD uint32_t f64_lo(double d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__double2loint(d);
+#else
+    uint64_t u;
+    memcpy(&u, &d, 8);
+    return (uint32_t)u;
+#endif
+}
+TOPO_HD uint32_t f64_hi(double d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__double2hiint(d);
+#else
+    uint64_t u;
+    memcpy(&u, &d, 8);
+    return (uint32_t)(u >> 32);
+#endif
+}
+
+// (ox, oy): the reference pixel of kind 1 -- any pixel at most 63 columns / 15 rows up and left of the pixels the record
+// will be asked about (k_resolve: the origin of the wave's strip).
+// (Every word is a local that is assigned on every path and stored once at the end: a struct that is zeroed first and
+// overwritten in the branches ends up in scratch memory.)
 TOPO_HD void resolve_setup(const TileDev& t, uint32_t tile_w, FastDiv div_hm1, uint32_t hm1, const ViewDev& view, int32_t W, int32_t H,
-                           uint32_t tri, uint32_t fan, const float* ndec, TriRecord& rec) {
+                           uint32_t tri, uint32_t fan, const float* ndec, int32_t ox, int32_t oy, TriRecord& rec) {
     ResolvedTri r;
     bool cut = false;
-    rec.kind = 0;
-    rec.u0 = rec.u1 = rec.u2 = rec.u3 = rec.u4 = rec.u5 = rec.u6 = rec.u7 = rec.u8 = rec.u9 = 0;
+    uint32_t kind = 0, iw0 = 0, iw1 = 0, iw2 = 0, iA = 0;
+    uint32_t u0 = 0, u1 = 0, u2 = 0, u3 = 0, u4 = 0, u5 = 0, u6 = 0, u7 = 0, u8 = 0, u9 = 0, u10 = 0, u11 = 0, u12 = 0, u13 = 0;
     if (resolve_vertices<true>(t, tile_w, div_hm1, hm1, view, W, H, tri, fan, ndec, r, &cut)) {
-        if (fan == 0) {
-            const int32_t X0 = r.s[0].X, Y0 = r.s[0].Y, X1 = r.s[1].X, Y1 = r.s[1].Y, X2 = r.s[2].X, Y2 = r.s[2].Y;
-            float iA = 0.0f;
-            if (spans_fit_int32(X0, Y0, X1, Y1, X2, Y2)) {
-                const int32_t area2 = TOPO_MUL24(X1 - X0, Y2 - Y0) - TOPO_MUL24(Y1 - Y0, X2 - X0);
-                if (area2 < 0) { iA = div_f(1.0f, (float)(-area2)); rec.kind = 1; }
-            } else {
-                const int64_t area2 = (int64_t)(X1 - X0) * (Y2 - Y0) - (int64_t)(Y1 - Y0) * (X2 - X0);
-                if (area2 < 0) { iA = div_f(1.0f, (float)(-area2)); rec.kind = 2; }
-            }
-            rec.u0 = (uint32_t)X0; rec.u1 = (uint32_t)X1; rec.u2 = (uint32_t)X2;
-            rec.u3 = (uint32_t)Y0; rec.u4 = (uint32_t)Y1; rec.u5 = (uint32_t)Y2;
-            rec.u6 = f_bits(div_f(1.0f, r.v[0].clip[3]));
-            rec.u7 = f_bits(div_f(1.0f, r.v[1].clip[3]));
-            rec.u8 = f_bits(div_f(1.0f, r.v[2].clip[3]));
-            rec.u9 = f_bits(iA);
+        const int32_t X0 = r.s[0].X, Y0 = r.s[0].Y, X1 = r.s[1].X, Y1 = r.s[1].Y, X2 = r.s[2].X, Y2 = r.s[2].Y;
+        const int64_t area2 = (int64_t)(X1 - X0) * (Y2 - Y0) - (int64_t)(Y1 - Y0) * (X2 - X0);
+        if (fan == 0 && area2 < 0) {
+            // edges e1 = v2 -> v0 (weight of v1), e2 = v0 -> v1 (weight of v2), as triangle_bary() numbers them
+            const int64_t cx = (int64_t)ox * 256 + 128, cy = (int64_t)oy * 256 + 128;
+            const int64_t dy1 = Y0 - Y2, dx1 = X0 - X2, dy2 = Y1 - Y0, dx2 = X1 - X0;
+            const int64_t C1 = dy1 * (cx - X2) - dx1 * (cy - Y2), C2 = dy2 * (cx - X0) - dx2 * (cy - Y0);
+            constexpr int64_t kLim = 1ll << 52;
+            const bool affine = -area2 < kLim && C1 > -kLim && C1 < kLim && C2 > -kLim && C2 < kLim;
+            const double A1 = (double)(dy1 * 256), B1 = (double)(dx1 * -256), A2 = (double)(dy2 * 256), B2 = (double)(dx2 * -256);
+            const double C1d = (double)C1, C2d = (double)C2, AR = (double)(-area2);
+            kind = affine ? 1u : 2u;
+            u0 = affine ? f64_lo(A1) : (uint32_t)X0; u1 = affine ? f64_hi(A1) : (uint32_t)X1;
+            u2 = affine ? f64_lo(B1) : (uint32_t)X2; u3 = affine ? f64_hi(B1) : (uint32_t)Y0;
+            u4 = affine ? f64_lo(C1d) : (uint32_t)Y1; u5 = affine ? f64_hi(C1d) : (uint32_t)Y2;
+            u6 = f64_lo(A2); u7 = f64_hi(A2); u8 = f64_lo(B2); u9 = f64_hi(B2); u10 = f64_lo(C2d); u11 = f64_hi(C2d);
+            u12 = f64_lo(AR); u13 = f64_hi(AR);
+            iA = f_bits(div_f(1.0f, (float)(-area2)));
+            iw0 = f_bits(div_f(1.0f, r.v[0].clip[3]));
+            iw1 = f_bits(div_f(1.0f, r.v[1].clip[3]));
+            iw2 = f_bits(div_f(1.0f, r.v[2].clip[3]));
         }
     } else if (cut) {
-        rec.kind = 3;
-        rec.u0 = f_bits(r.v[0].clip[0]); rec.u1 = f_bits(r.v[0].clip[1]); rec.u2 = f_bits(r.v[0].clip[3]);
-        rec.u3 = f_bits(r.v[1].clip[0]); rec.u4 = f_bits(r.v[1].clip[1]); rec.u5 = f_bits(r.v[1].clip[3]);
-        rec.u6 = f_bits(r.v[2].clip[0]); rec.u7 = f_bits(r.v[2].clip[1]); rec.u8 = f_bits(r.v[2].clip[3]);
+        kind = 3;
+        const float *c0 = r.v[0].clip, *c1 = r.v[1].clip, *c2 = r.v[2].clip;      // the determinants of homogeneous_weights()
+        u0 = f_bits(det2(c1[1], c2[3], c1[3], c2[1])); u1 = f_bits(det2(c1[3], c2[0], c1[0], c2[3])); u2 = f_bits(det2(c1[0], c2[1], c1[1], c2[0]));
+        u3 = f_bits(det2(c2[1], c0[3], c2[3], c0[1])); u4 = f_bits(det2(c2[3], c0[0], c2[0], c0[3])); u5 = f_bits(det2(c2[0], c0[1], c2[1], c0[0]));
+        u6 = f_bits(det2(c0[1], c1[3], c0[3], c1[1])); u7 = f_bits(det2(c0[3], c1[0], c0[0], c1[3])); u8 = f_bits(det2(c0[0], c1[1], c0[1], c1[0]));
     }
+    rec.kind = kind;
+    rec.u0 = u0; rec.u1 = u1; rec.u2 = u2; rec.u3 = u3; rec.u4 = u4; rec.u5 = u5; rec.u6 = u6; rec.u7 = u7; rec.u8 = u8; rec.u9 = u9;
+    rec.u10 = u10; rec.u11 = u11; rec.u12 = u12; rec.u13 = u13;
+    rec.iw0 = iw0; rec.iw1 = iw1; rec.iw2 = iw2; rec.iA = iA;
     rec.wx0 = f_bits(r.v[0].wpos.x); rec.wx1 = f_bits(r.v[1].wpos.x); rec.wx2 = f_bits(r.v[2].wpos.x);
     rec.wy0 = f_bits(r.v[0].wpos.y); rec.wy1 = f_bits(r.v[1].wpos.y); rec.wy2 = f_bits(r.v[2].wpos.y);
     rec.n0x = f_bits(r.v[0].wnrm.x); rec.n0y = f_bits(r.v[0].wnrm.y); rec.n0z = f_bits(r.v[0].wnrm.z);
@@ -674,32 +728,42 @@ TOPO_HD void resolve_setup(const TileDev& t, uint32_t tile_w, FastDiv div_hm1, u
     rec.n2x = f_bits(r.v[2].wnrm.x); rec.n2y = f_bits(r.v[2].wnrm.y); rec.n2z = f_bits(r.v[2].wnrm.z);
 }
 
-// world_pos.xy and the world normal of the fragment at (px, py); false = no varyings (the pixel keeps the cleared colour)
-TOPO_HD bool resolve_pixel(const TriRecord& rec, int32_t W, int32_t H, int32_t px, int32_t py, float& wposx, float& wposy, f3& wnrm) {
+// Where a pixel is, in the three forms the record kinds use: k_resolve keeps the column forms per lane and strip, the row
+// forms per row (wave-uniform).
+struct PixelAt {
+    int32_t px, py;        // kind 2
+    double dx, dy;         // kind 1: px - ox, py - oy of the record's reference pixel
+    float gx, gy;          // kind 3: the pixel centre in normalised device coordinates (homogeneous_weights)
+};
+TOPO_HD float pixel_gx(int32_t px, float two_over_w) { return fmaf((float)px + 0.5f, two_over_w, -1.0f); }      // two_over_w = div_f(2, W)
+TOPO_HD float pixel_gy(int32_t py, float two_over_h) { return fmaf(-((float)py + 0.5f), two_over_h, 1.0f); }
+TOPO_HD PixelAt pixel_at(int32_t W, int32_t H, int32_t px, int32_t py, int32_t ox, int32_t oy) {
+    return PixelAt{px, py, (double)(px - ox), (double)(py - oy), pixel_gx(px, div_f(2.0f, (float)W)), pixel_gy(py, div_f(2.0f, (float)H))};
+}
+
+// world_pos.xy and the world normal of the fragment at `at`; false = no varyings (the pixel keeps the cleared colour)
+TOPO_HD bool resolve_pixel(const TriRecord& rec, const PixelAt& at, float& wposx, float& wposy, f3& wnrm) {
     float q0, q1, q2;
     if (rec.kind == 1u || rec.kind == 2u) {
-        const int32_t X0 = (int32_t)rec.u0, X1 = (int32_t)rec.u1, X2 = (int32_t)rec.u2, Y0 = (int32_t)rec.u3, Y1 = (int32_t)rec.u4, Y2 = (int32_t)rec.u5;
-        const int32_t cx = px * 256 + 128, cy = py * 256 + 128;
-        const float iA = bits_f(rec.u9);
-        float b0, b1, b2;
+        float f0, f1, f2;
         if (rec.kind == 1u) {
-            b0 = (float)(TOPO_MUL24(Y2 - Y1, cx - X1) - TOPO_MUL24(X2 - X1, cy - Y1)) * iA;
-            b1 = (float)(TOPO_MUL24(Y0 - Y2, cx - X2) - TOPO_MUL24(X0 - X2, cy - Y2)) * iA;
-            b2 = (float)(TOPO_MUL24(Y1 - Y0, cx - X0) - TOPO_MUL24(X1 - X0, cy - Y0)) * iA;
+            const double F1 = fma(f64_from_words(rec.u0, rec.u1), at.dx, fma(f64_from_words(rec.u2, rec.u3), at.dy, f64_from_words(rec.u4, rec.u5)));
+            const double F2 = fma(f64_from_words(rec.u6, rec.u7), at.dx, fma(f64_from_words(rec.u8, rec.u9), at.dy, f64_from_words(rec.u10, rec.u11)));
+            const double F0 = (f64_from_words(rec.u12, rec.u13) - F1) - F2;
+            f0 = (float)F0; f1 = (float)F1; f2 = (float)F2;
         } else {
-            b0 = (float)((int64_t)(Y2 - Y1) * (cx - X1) - (int64_t)(X2 - X1) * (cy - Y1)) * iA;
-            b1 = (float)((int64_t)(Y0 - Y2) * (cx - X2) - (int64_t)(X0 - X2) * (cy - Y2)) * iA;
-            b2 = (float)((int64_t)(Y1 - Y0) * (cx - X0) - (int64_t)(X1 - X0) * (cy - Y0)) * iA;
+            const int32_t X0 = (int32_t)rec.u0, X1 = (int32_t)rec.u1, X2 = (int32_t)rec.u2, Y0 = (int32_t)rec.u3, Y1 = (int32_t)rec.u4, Y2 = (int32_t)rec.u5;
+            const int32_t cx = at.px * 256 + 128, cy = at.py * 256 + 128;
+            f0 = (float)((int64_t)(Y2 - Y1) * (cx - X1) - (int64_t)(X2 - X1) * (cy - Y1));
+            f1 = (float)((int64_t)(Y0 - Y2) * (cx - X2) - (int64_t)(X0 - X2) * (cy - Y2));
+            f2 = (float)((int64_t)(Y1 - Y0) * (cx - X0) - (int64_t)(X1 - X0) * (cy - Y0));
         }
-        q0 = b0 * bits_f(rec.u6); q1 = b1 * bits_f(rec.u7); q2 = b2 * bits_f(rec.u8);
+        const float iA = bits_f(rec.iA);
+        q0 = (f0 * iA) * bits_f(rec.iw0); q1 = (f1 * iA) * bits_f(rec.iw1); q2 = (f2 * iA) * bits_f(rec.iw2);
     } else if (rec.kind == 3u) {
-        const float gx = fmaf((float)px + 0.5f, div_f(2.0f, (float)W), -1.0f);
-        const float gy = fmaf(-((float)py + 0.5f), div_f(2.0f, (float)H), 1.0f);
-        const float c0x = bits_f(rec.u0), c0y = bits_f(rec.u1), c0w = bits_f(rec.u2), c1x = bits_f(rec.u3), c1y = bits_f(rec.u4), c1w = bits_f(rec.u5);
-        const float c2x = bits_f(rec.u6), c2y = bits_f(rec.u7), c2w = bits_f(rec.u8);
-        q0 = fmaf(det2(c1y, c2w, c1w, c2y), gx, fmaf(det2(c1w, c2x, c1x, c2w), gy, det2(c1x, c2y, c1y, c2x)));
-        q1 = fmaf(det2(c2y, c0w, c2w, c0y), gx, fmaf(det2(c2w, c0x, c2x, c0w), gy, det2(c2x, c0y, c2y, c0x)));
-        q2 = fmaf(det2(c0y, c1w, c0w, c1y), gx, fmaf(det2(c0w, c1x, c0x, c1w), gy, det2(c0x, c1y, c0y, c1x)));
+        q0 = fmaf(bits_f(rec.u0), at.gx, fmaf(bits_f(rec.u1), at.gy, bits_f(rec.u2)));
+        q1 = fmaf(bits_f(rec.u3), at.gx, fmaf(bits_f(rec.u4), at.gy, bits_f(rec.u5)));
+        q2 = fmaf(bits_f(rec.u6), at.gx, fmaf(bits_f(rec.u7), at.gy, bits_f(rec.u8)));
     } else {
         return false;
     }
