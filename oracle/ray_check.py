@@ -83,11 +83,12 @@ def camera_basis(eye, yaw, pitch):
     return f, s, u
 
 
-def ray_cast(tiles, eye, yaw, pitch, fov_y, W, H, chunk=256):
+def ray_cast(tiles, eye, yaw, pitch, fov_y, W, H, chunk=256, with_bary=False):
     """tiles: [(heights f32 [h,w], raster_point, model_point, pixel_scale)] in DRAW order.
     Returns per pixel: depth_ndc (1.0 = no hit), winner (tile_rank * 2(w-1)(h-1) + triangle, -1 = none), the smallest
     barycentric of the winning hit (how far inside its triangle the pixel centre lies), and the view depth of the
-    nearest hit when back faces are NOT culled (np.inf = none)."""
+    nearest hit when back faces are NOT culled (np.inf = none).  with_bary: also the weights of the winning triangle's second
+    and third vertex at the hit point (barycentrics in the triangle's own plane = perspective-correct interpolation weights)."""
     eye = np.asarray(eye, np.float64)
     f, s, u = camera_basis(eye, yaw, pitch)
     th = math.tan(0.5 * fov_y)
@@ -117,6 +118,7 @@ def ray_cast(tiles, eye, yaw, pitch, fov_y, W, H, chunk=256):
     winner = np.full(n_pix, -1, np.int64)
     minbary = np.zeros(n_pix)
     any_depth = np.full(n_pix, np.inf)
+    wu, wv = np.zeros(n_pix), np.zeros(n_pix)
     for lo in range(0, n_pix, chunk):
         d = D[lo:lo + chunk]                               # [c,3]
         # Moeller-Trumbore with the ray origin at the (translated) origin: o - v0 = -V0
@@ -144,6 +146,10 @@ def ray_cast(tiles, eye, yaw, pitch, fov_y, W, H, chunk=256):
         winner[lo:lo + chunk] = np.where(ok, ids[k], -1)
         b1, b2 = bu[rows, k], bv[rows, k]
         minbary[lo:lo + chunk] = np.where(ok, np.minimum(np.minimum(b1, b2), 1.0 - b1 - b2), 0.0)
+        wu[lo:lo + chunk] = np.where(ok, b1, 0.0)
+        wv[lo:lo + chunk] = np.where(ok, b2, 0.0)
+    if with_bary:
+        return depth.reshape(H, W), winner.reshape(H, W), minbary.reshape(H, W), any_depth.reshape(H, W), wu.reshape(H, W), wv.reshape(H, W)
     return depth.reshape(H, W), winner.reshape(H, W), minbary.reshape(H, W), any_depth.reshape(H, W)
 
 

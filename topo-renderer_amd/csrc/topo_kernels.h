@@ -12,7 +12,10 @@ namespace topo {
 // so a 1200x1200 COP90 tile gives 20 x 80 blocks with no sliver blocks.
 constexpr uint32_t kBCX = 60, kBCY = 15;
 constexpr uint32_t kVX = kBCX + 1, kVY = kBCY + 1;
-constexpr uint32_t kResolveBlockW = 64, kResolveBlockH = 16;   // k_resolve's pixel blocks
+#ifndef TOPO_RESOLVE_RPW
+#define TOPO_RESOLVE_RPW 8      // pixel rows per wave of k_resolve (4 or 8)
+#endif
+constexpr uint32_t kResolveBlockW = 64, kResolveBlockH = 4 * TOPO_RESOLVE_RPW;   // k_resolve's pixel blocks: four waves, a 64 x RPW strip each
 
 struct WorkItem {          // one (view, tile, block) that survived the frustum cull
     uint32_t view_rank;    // view << 16 | tile rank (draw order)

@@ -1043,9 +1043,10 @@ __global__ __launch_bounds__(256) void k_raster_big(FrameParams P) {
 // the colour format is a template parameter, a record's kind-specific part is affine in the pixel (TriRecord), the
 // positions of the ring entries are lane constants, and a row none of whose pixels can have a non-zero contour factor
 // (decided by one comparison per pixel that can only err towards the long route) skips the post pass's divisions.
-constexpr int kRPW = 4;                            // pixel rows per wave
+constexpr int kRPW = TOPO_RESOLVE_RPW;             // pixel rows per wave
 constexpr int kResolveRows = 4 * kRPW;
 static_assert(kResolveRows == (int)kResolveBlockH && kResolveBlockW == 64u, "the host sizes k_resolve's block grid from these");
+static_assert(kRPW == 4 || kRPW == 8, "RowN below names the rows of a wave");
 #ifndef TOPO_RESOLVE_RECS
 #define TOPO_RESOLVE_RECS 32
 #endif
@@ -1053,15 +1054,18 @@ constexpr uint32_t kRecCap = TOPO_RESOLVE_RECS;    // triangle records per wave
 #ifndef TOPO_RESOLVE_WGS
 #define TOPO_RESOLVE_WGS 4
 #endif
-static_assert(kRPW == 4, "Row4 below names the four rows of a wave");
 // One value per row of a wave.  Named members, not an array: an array indexed by a loop variable goes to scratch memory.
 template <typename T>
-struct Row4 {
-    T a, b, c, d;
+struct RowN {
+    T a, b, c, d, e, f, g, h;
 };
-#define TOPO_ROWS4(X) X(0, a) X(1, b) X(2, c) X(3, d)
+#if TOPO_RESOLVE_RPW == 8
+#define TOPO_ROWS(X) X(0, a) X(1, b) X(2, c) X(3, d) X(4, e) X(5, f) X(6, g) X(7, h)
+#else
+#define TOPO_ROWS(X) X(0, a) X(1, b) X(2, c) X(3, d)
+#endif
 
-struct ResolveBlock {          // wave-uniform description of one 64 x 16 block
+struct ResolveBlock {          // wave-uniform description of one 64 x (4 kRPW) block
     uint32_t view;
     int32_t bx, by;            // pixel origin
 };
@@ -1070,8 +1074,8 @@ __device__ __forceinline__ ResolveBlock resolve_block(const FrameParams& P, uint
     const uint32_t row = P.rblocks_x > 1u ? fastdiv(in_view, P.div_rblocks_x) : in_view;
     return ResolveBlock{view, (int32_t)(in_view - row * P.rblocks_x) * 64, (int32_t)row * kResolveRows};
 }
-// Did anything write a key of wave `wave`'s strip (rows 4 wave .. 4 wave + 3 of the block) or its halo?  Every row of strip +
-// halo spans at most three 64-key segments; t < 18 names one (row, segment) mark.
+// Did anything write a key of wave `wave`'s strip (rows kRPW wave .. kRPW wave + kRPW - 1 of the block) or its halo?  Every row
+// of strip + halo spans at most three 64-key segments; t < kStripMarks names one (row, segment) mark.
 constexpr uint32_t kStripMarks = (kRPW + 2) * 3;
 __device__ __forceinline__ bool resolve_strip_marked(const FrameParams& P, const ResolveBlock& B, uint32_t wave, uint32_t t) {
     const int32_t row = (int32_t)t / 3, k = (int32_t)t - row * 3;
@@ -1085,11 +1089,11 @@ __device__ __forceinline__ bool resolve_strip_marked(const FrameParams& P, const
     const bool mark = TOPO_CHK(P.counters, at < (((size_t)P.n_views * P.W * P.H + 63) >> 6), 12u, at) ? P.dirty[at] != 0 : false;
     return seg <= last && mark;
 }
-// What a lane holds of a strip: the keys of its own four pixels and up to three depths of the ring around the strip:
-// ring0 = the pixel above the lane's column (row -1), ring1 = the pixel below it (row 4), ring2 (lanes 0..11) = columns -1
-// and 64 of rows -1 .. 4 (lane = 2 (row + 1) + side).
+// What a lane holds of a strip: the keys of its own kRPW pixels and up to three depths of the ring around the strip:
+// ring0 = the pixel above the lane's column (row -1), ring1 = the pixel below it (row kRPW), ring2 (lanes 0 .. 2 kRPW + 3) =
+// columns -1 and 64 of rows -1 .. kRPW (lane = 2 (row + 1) + side).
 struct ResolveKeys {
-    Row4<uint32_t> id, raw;
+    RowN<uint32_t> id, raw;
     uint32_t ring0, ring1, ring2;
 };
 constexpr uint32_t kRing2Lanes = 2 * (kRPW + 2);
@@ -1108,7 +1112,7 @@ __device__ __forceinline__ void resolve_load_keys(const FrameParams& P, const Re
         K.id.m = (uint32_t)key;                                           \
         K.raw.m = (uint32_t)(key >> 32);                                  \
     }
-    TOPO_ROWS4(TOPO_X)
+    TOPO_ROWS(TOPO_X)
 #undef TOPO_X
     // the ring: depth words only; every lane loads three (clamped positions: no branches around the loads)
     K.ring0 = reinterpret_cast<const uint32_t*>(col + (size_t)ym * P.W)[1];
@@ -1120,6 +1124,11 @@ __device__ __forceinline__ void resolve_load_keys(const FrameParams& P, const Re
         y = y < 0 ? 0 : (y > P.H - 1 ? P.H - 1 : y);
         K.ring2 = reinterpret_cast<const uint32_t*>(vis + (size_t)y * P.W + x)[1];
     }
+}
+// the winner id of one pixel again (rows shaded in one step per pixel, later record groups: both rare)
+__device__ __forceinline__ uint32_t resolve_reload_id(const FrameParams& P, const ResolveBlock& B, int32_t px, int32_t py) {
+    const int32_t cx = px > P.W - 1 ? P.W - 1 : px, cy = py > P.H - 1 ? P.H - 1 : py;
+    return (uint32_t)P.vis[(size_t)B.view * P.W * P.H + (size_t)cy * P.W + cx];
 }
 
 template <bool kBgra>
@@ -1154,10 +1163,10 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// The four waves of a workgroup share the tables and the list of 64 x 16 blocks, and nothing else: wave w takes rows
-// 4w .. 4w+3 of every block (a 64 x 4 strip) with its own halo, its own depth tile and its own record table, at its own pace --
-// no barrier after the tables are in place.  (With one depth tile per block, two barriers per block made every wave wait for the
-// block's slowest: 29 % of all wave time.)
+// The four waves of a workgroup share the tables and the list of blocks, and nothing else: wave w takes rows kRPW w .. of every
+// block (a 64 x kRPW strip) with its own halo, its own depth tile and its own record table, at its own pace -- no barrier after
+// the tables are in place.  (With one depth tile per block, two barriers per block made every wave wait for the block's
+// slowest: 29 % of all wave time.)
 // kSrgb: the targets are *Srgb formats (encode on store, decode on sample); otherwise plain unorm8.  kBgra: channel order.
 template <bool kSrgb, bool kBgra>
 __global__ __launch_bounds__(256, TOPO_RESOLVE_WGS) void k_resolve(FrameParams P, OutputParams O) {
@@ -1167,9 +1176,8 @@ __global__ __launch_bounds__(256, TOPO_RESOLVE_WGS) void k_resolve(FrameParams P
     __shared__ uint32_t s_lut[1024];   // 4096 one-byte bins of srgb_encode_lut
     __shared__ float s_lin[4][kRPW + 2][66];                 // per wave: linear depth of the strip + halo
     __shared__ uint32_t s_rec[4][kTriRecordWords][kRecCap];  // per wave: the records, word-major (lanes with consecutive slots hit consecutive banks)
-    __shared__ uint32_t s_uid[4][kRecCap];                   // per wave: the distinct winner ids
-    __shared__ uint32_t s_id[4][kRPW][64];                   // per wave and pixel: the winner id ...
-    __shared__ uint16_t s_slot[4][kRPW][64];                 // ... and the number of its entry among the strip's table entries (0xFFFF: no winner)
+    __shared__ uint32_t s_uid[4][kRecCap];                   // per wave: the distinct winner ids of a group of rows
+    __shared__ uint8_t s_slot[4][kRPW][64];                  // per wave and pixel: the number of its entry among the strip's table entries (0xFF: none)
     const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int32_t tx = (int32_t)lane;
     // Blocks are dealt out with a static stride: workgroup g takes blocks g, g + grid, g + 2 grid, ... -- a sample of every
@@ -1195,8 +1203,7 @@ __global__ __launch_bounds__(256, TOPO_RESOLVE_WGS) void k_resolve(FrameParams P
 #define TOPO_PROF(slot)
 #endif
     float (*const lin_tile)[66] = s_lin[wave];
-    uint32_t (*const id_tile)[64] = s_id[wave];
-    uint16_t (*const slot_tile)[64] = s_slot[wave];
+    uint8_t (*const slot_tile)[64] = s_slot[wave];
     const int32_t sy0 = kRPW * (int32_t)wave;      // the strip's first row within its block
     // lane constants: the pixel's column as a double (TriRecord kind 1), the lane's entry of the ring's side columns
     const double lane_d = (double)tx;
@@ -1223,60 +1230,54 @@ __global__ __launch_bounds__(256, TOPO_RESOLVE_WGS) void k_resolve(FrameParams P
         // the untouched strips are pure stores: spread over the marked strips' iterations, so that their bandwidth hides
         // under the shading
         const uint32_t fills_per_iter = n_marked ? (n_clear + n_marked - 1) / n_marked : n_clear;
+        // The keys of strip i + 1 are requested once strip i's keys have been consumed (depths into the LDS tile and the depth
+        // output, ids into entry numbers): they travel under strip i's record pass and shading -- the bulk of a strip's time --
+        // in the registers strip i's keys have just left.
         ResolveKeys K;
-        uint32_t j_next = 0;
-        if (mm) { j_next = pop_bit(mm); resolve_load_keys(P, block_of(j_next), lane, wave, K); }
-        for (uint32_t i = 0; i < (n_marked ? n_marked : 1u); ++i) {
+        uint32_t j_cur = 0;
+        bool have = mm != 0ull;
+        if (have) { j_cur = pop_bit(mm); resolve_load_keys(P, block_of(j_cur), lane, wave, K); }
+        while (have) {
+#ifdef TOPO_RESOLVE_EARLY_PREFETCH      // experiment build: the next strip's keys requested at the top of the iteration, into registers of their own
             ResolveKeys Kn;
-            const uint32_t j_cur = j_next;
-            if (mm) { j_next = pop_bit(mm); resolve_load_keys(P, block_of(j_next), lane, wave, Kn); }      // in flight while strip i is shaded
-            for (uint32_t f = 0; f < fills_per_iter && mc; ++f) resolve_fill_sky<kBgra>(P, O, block_of(pop_bit(mc)), lane, wave);
-            TOPO_PROF(1)  // issue of the next keys + sky fills
-            if (i >= n_marked) break;
+            const bool more = mm != 0ull;
+            uint32_t j_next = 0;
+            if (more) { j_next = pop_bit(mm); resolve_load_keys(P, block_of(j_next), lane, wave, Kn); }
+#endif
             const ResolveBlock B = block_of(j_cur);
             const int32_t px = B.bx + tx, y0 = B.by + sy0;
             const bool in_x = px < P.W;        // lanes beyond the target's right edge stay: they compute triangle records
             const int32_t n_rows = P.H - y0 < kRPW ? P.H - y0 : kRPW;      // rows of the strip inside the target (>= 1)
-            const bool terrain = K.raw.a != 0x3F800000u || K.raw.b != 0x3F800000u || K.raw.c != 0x3F800000u || K.raw.d != 0x3F800000u ||
-                                 K.ring0 != 0x3F800000u || K.ring1 != 0x3F800000u || (lane < kRing2Lanes && K.ring2 != 0x3F800000u);
+            bool terrain = K.ring0 != 0x3F800000u || K.ring1 != 0x3F800000u || (lane < kRing2Lanes && K.ring2 != 0x3F800000u);
+#define TOPO_X(r, m) terrain |= K.raw.m != 0x3F800000u;
+            TOPO_ROWS(TOPO_X)
+#undef TOPO_X
             TOPO_PROF(2)  // wait for this strip's keys
-            if (__ballot(terrain) == 0ull) {   // marked, but every key still cleared (a mark covers 64 keys): the cleared texel and depth 1
-                resolve_fill_sky<kBgra>(P, O, B, lane, wave);
-                K = Kn;
-                continue;
-            }
-            wave_lds_fence();                  // (the previous strip's reads of the tiles are done)
+            const bool any_terrain = __ballot(terrain) != 0ull;
+            RowN<uint32_t> n_row;
+            uint32_t n_all = 0;            // table entries of the strip
+            if (any_terrain) {
+                wave_lds_fence();              // (the previous strip's reads of the tiles are done)
 #define TOPO_X(r, m) lin_tile[r + 1][tx + 1] = linear_depth(bits_f(K.raw.m));
-            TOPO_ROWS4(TOPO_X)
+                TOPO_ROWS(TOPO_X)
 #undef TOPO_X
-            lin_tile[0][tx + 1] = linear_depth(bits_f(K.ring0));
-            lin_tile[kRPW + 1][tx + 1] = linear_depth(bits_f(K.ring1));
-            {
-                const float l2 = linear_depth(bits_f(K.ring2));
-                if (lane < kRing2Lanes) *ring2_at = l2;
-            }
-            TOPO_PROF(4)  // linear depths
-            uint8_t* rgba_p = O.rgba + (size_t)B.view * O.rgba_view_stride + (size_t)y0 * O.rgba_pitch + (size_t)px * 4;
-            // the depth output is the key's depth word: stored now, so that the four words are not held through the shading
-            if (in_x && O.depth) {
-                uint8_t* dp = reinterpret_cast<uint8_t*>(O.depth) + (size_t)B.view * O.depth_view_stride + (size_t)y0 * O.depth_pitch + (size_t)px * 4;
+                lin_tile[0][tx + 1] = linear_depth(bits_f(K.ring0));
+                lin_tile[kRPW + 1][tx + 1] = linear_depth(bits_f(K.ring1));
+                {
+                    const float l2 = linear_depth(bits_f(K.ring2));
+                    if (lane < kRing2Lanes) *ring2_at = l2;
+                }
+                TOPO_PROF(4)  // linear depths
+                // the depth output is the key's depth word
+                if (in_x && O.depth) {
+                    uint8_t* dp = reinterpret_cast<uint8_t*>(O.depth) + (size_t)B.view * O.depth_view_stride + (size_t)y0 * O.depth_pitch + (size_t)px * 4;
 #define TOPO_X(r, m) if (r < n_rows) { *reinterpret_cast<uint32_t*>(dp) = K.raw.m; dp += O.depth_pitch; }
-                TOPO_ROWS4(TOPO_X)
+                    TOPO_ROWS(TOPO_X)
 #undef TOPO_X
-            }
-            const ViewDev& view = P.views[B.view];
-            // what fs_main reads of the view, once per strip and wave-uniform: left to the compiler these are re-loaded in every
-            // row (it cannot prove the output stores do not alias them) behind an s_waitcnt vmcnt(0) that also waits for the
-            // previous row's stores to land
-            const f3 sun = {unif(view.sun[0]), unif(view.sun[1]), unif(view.sun[2])};
-            const float cam_x = unif(view.cam_x), cam_y = unif(view.cam_y);
-            const int32_t view_mode = uni(view.view_mode);
-            // ---- the distinct winners of this wave's pixels: a lane opens an entry where its id differs from its left
-            // neighbour's.  Entries are numbered over the strip's rows that fit the table; n_row = entries of a row.  What the
-            // row loop needs of a pixel waits in LDS: its winner id and its entry number.
-            Row4<uint32_t> n_row;
-            uint32_t n_all = 0;
-            {
+                }
+                // ---- the distinct winners of this wave's pixels: a lane opens an entry where its id differs from its left
+                // neighbour's.  Entries are numbered over the strip's rows that are shaded from the table (rows with at most kRecCap
+                // entries, while the numbers fit a byte); n_row = entries of a row.  A pixel's entry number waits in LDS.
 #define TOPO_X(r, m)                                                                                                            \
     {                                                                                                                           \
         const bool valid = in_x && r < n_rows && K.id.m != kNoTri;                                                              \
@@ -1284,32 +1285,58 @@ __global__ __launch_bounds__(256, TOPO_RESOLVE_WGS) void k_resolve(FrameParams P
         const bool leader = valid && (lane == 0 || K.id.m != left);                                                             \
         const uint64_t mask = __ballot(leader);                                                                                 \
         n_row.m = (uint32_t)__popcll(mask);                                                                                     \
+        if (n_all + n_row.m > 254u) n_row.m = kRecCap + 1u; /* (entry numbers are bytes: such a row is shaded in one step per pixel) */ \
         const uint32_t slot = n_all + (uint32_t)__popcll(mask & ((2ull << lane) - 1ull)) - 1u; /* valid lanes: the last leader at or before them */ \
-        id_tile[r][tx] = valid ? K.id.m : kNoTri;                                                                               \
-        slot_tile[r][tx] = (uint16_t)(valid ? slot : 0xFFFFu);                                                                  \
+        slot_tile[r][tx] = (uint8_t)(valid && n_row.m <= kRecCap ? slot : 0xFFu);                                               \
         if (leader && n_row.m <= kRecCap && slot < kRecCap) s_uid[wave][slot] = K.id.m; /* the first group's ids (later groups: below) */ \
         n_all += n_row.m <= kRecCap ? n_row.m : 0u;                                                                             \
     }
-                TOPO_ROWS4(TOPO_X)
+                TOPO_ROWS(TOPO_X)
 #undef TOPO_X
+                wave_lds_fence();
             }
-            wave_lds_fence();
+#ifndef TOPO_RESOLVE_EARLY_PREFETCH
+            // ---- this strip's keys are consumed: request the next strip's
+            const bool more = mm != 0ull;
+            uint32_t j_next = 0;
+            if (more) { j_next = pop_bit(mm); resolve_load_keys(P, block_of(j_next), lane, wave, K); }
+#endif
+            for (uint32_t f = 0; f < fills_per_iter && mc; ++f) resolve_fill_sky<kBgra>(P, O, block_of(pop_bit(mc)), lane, wave);
+            TOPO_PROF(1)  // issue of the next keys + sky fills
+            if (!any_terrain) {                // marked, but every key still cleared (a mark covers 64 keys): the cleared texel and depth 1
+                resolve_fill_sky<kBgra>(P, O, B, lane, wave);
+                have = more;
+                j_cur = j_next;
+#ifdef TOPO_RESOLVE_EARLY_PREFETCH
+                K = Kn;
+#endif
+                continue;
+            }
+            uint8_t* rgba_p = O.rgba + (size_t)B.view * O.rgba_view_stride + (size_t)y0 * O.rgba_pitch + (size_t)px * 4;
+            const ViewDev& view = P.views[B.view];
+            // what fs_main reads of the view, once per strip and wave-uniform: left to the compiler these are re-loaded in every
+            // row (it cannot prove the output stores do not alias them) behind an s_waitcnt vmcnt(0) that also waits for the
+            // previous row's stores to land
+            const f3 sun = {unif(view.sun[0]), unif(view.sun[1]), unif(view.sun[2])};
+            const float cam_x = unif(view.cam_x), cam_y = unif(view.cam_y);
+            const int32_t view_mode = uni(view.view_mode);
 #ifdef TOPO_RESOLVE_STATS      // experiment build: how well do winners share?  counters[12] entries, [13] waves with terrain, [14] groups, [15] terrain pixels
             {
                 uint32_t npx = 0;
-#define TOPO_X(r, m) npx += (uint32_t)__popcll(__ballot(in_x && K.id.m != kNoTri));
-                TOPO_ROWS4(TOPO_X)
-#undef TOPO_X
+                for (int32_t r = 0; r < n_rows; ++r) npx += (uint32_t)__popcll(__ballot(in_x && slot_tile[r][tx] != 0xFFu));
                 if (lane == 0 && n_all) { atomicAdd(&P.counters[12], n_all); atomicAdd(&P.counters[13], 1u); atomicAdd(&P.counters[15], npx); }
             }
 #endif
             const float gx = pixel_gx(px, two_over_w);
-            // Rows are taken in groups of consecutive rows whose table entries fit the table (near field: all four rows in one
+            // Rows are taken in groups of consecutive rows whose table entries fit the table (near field: all rows in one
             // group, a handful of records); a row with more entries than the table holds is a group of its own, shaded in
             // one step per pixel (resolve_varyings), as every row was in round 1.
             int32_t r0 = 0;
             uint32_t gbase = 0;            // table entries of the groups before this one
-            const bool one_group = n_all <= kRecCap && n_row.a <= kRecCap && n_row.b <= kRecCap && n_row.c <= kRecCap && n_row.d <= kRecCap;
+            bool one_group = n_all <= kRecCap;
+#define TOPO_X(r, m) one_group = one_group && n_row.m <= kRecCap;
+            TOPO_ROWS(TOPO_X)
+#undef TOPO_X
 #pragma unroll 1
             while (r0 < n_rows) {
                 int32_t r1;
@@ -1322,17 +1349,18 @@ __global__ __launch_bounds__(256, TOPO_RESOLVE_WGS) void k_resolve(FrameParams P
                     r1 = r0;
                     cnt = 0;
 #define TOPO_X(r, m) if (r >= r0 && r == r1 && n_row.m <= kRecCap && cnt + n_row.m <= kRecCap) { cnt += n_row.m; r1 = r + 1; }
-                    TOPO_ROWS4(TOPO_X)
+                    TOPO_ROWS(TOPO_X)
 #undef TOPO_X
+                    if (r1 > n_rows) r1 = n_rows;
                     if (r1 == r0) {            // the row at r0 alone exceeds the table
                         table = false;
                         r1 = r0 + 1;
                     } else if (gbase != 0u) {
                         // a later group: its ids were not listed above (their entry numbers lie beyond the table): listed now -- a
-                        // lane is the leader of its entry iff its left neighbour has another one
+                        // lane is the leader of its entry iff its left neighbour has another one; the id is read again
                         for (int32_t r = r0; r < r1; ++r) {
                             const uint32_t e = slot_tile[r][tx], el = (uint32_t)__shfl_up((int)e, 1);
-                            if (e != 0xFFFFu && (lane == 0 || e != el) && TOPO_CHK(P.counters, e - gbase < kRecCap, 15u, e)) s_uid[wave][e - gbase] = id_tile[r][tx];
+                            if (e != 0xFFu && (lane == 0 || e != el) && TOPO_CHK(P.counters, e - gbase < kRecCap, 15u, e)) s_uid[wave][e - gbase] = resolve_reload_id(P, B, px, y0 + r);
                         }
                     }
                 }
@@ -1359,7 +1387,8 @@ __global__ __launch_bounds__(256, TOPO_RESOLVE_WGS) void k_resolve(FrameParams P
 #pragma unroll 1
                 for (int32_t r = r0; r < r1; ++r, rgba_p += O.rgba_pitch) {
                     const int32_t py = y0 + r;
-                    const uint32_t sel = table ? (uint32_t)slot_tile[r][tx] : id_tile[r][tx];      // the pixel's entry number / its winner id
+                    // the pixel's entry number (rows shaded from the table) or its winner id
+                    const uint32_t sel = table ? (uint32_t)slot_tile[r][tx] : (in_x ? resolve_reload_id(P, B, px, py) : kNoTri);
                     // the contour taps first: they depend on nothing, so their LDS trip overlaps the record's
                     float ln[8];
                     {
@@ -1375,7 +1404,7 @@ __global__ __launch_bounds__(256, TOPO_RESOLVE_WGS) void k_resolve(FrameParams P
                     const float lin_c = lin_tile[r + 1][tx + 1];
                     // render target texel (Rgba8UnormSrgb): the cleared value or the shaded winner
                     uint32_t c8 = P.sky_c8;
-                    if (sel != (table ? 0xFFFFu : kNoTri)) {
+                    if (sel != (table ? 0xFFu : kNoTri)) {
                         float lin[4] = {0.0f, 0.71f, 0.885f, 1.0f};
                         f3 wpos = {0.0f, 0.0f, 0.0f}, wnrm;
                         bool ok;
@@ -1388,6 +1417,9 @@ __global__ __launch_bounds__(256, TOPO_RESOLVE_WGS) void k_resolve(FrameParams P
 #undef TOPO_X
                             const PixelAt at = {px, py, lane_d, (double)r, gx, pixel_gy(py, two_over_h)};
                             ok = resolve_pixel(rec, at, wpos.x, wpos.y, wnrm);
+#ifdef TOPO_RESOLVE_STATS
+                            { const uint32_t n3 = (uint32_t)__popcll(__ballot(rec.kind == 3u)); if (n3 && lane == (uint32_t)__builtin_ctzll(__ballot(true))) atomicAdd(&P.counters[11], n3); }
+#endif
                         } else {
                             const uint32_t draw = sel >> 1, fan = sel & 1u;
                             const uint32_t rank = fastdiv(draw, P.div_tris), tri = draw - rank * P.tris_per_tile;
@@ -1405,14 +1437,22 @@ __global__ __launch_bounds__(256, TOPO_RESOLVE_WGS) void k_resolve(FrameParams P
 #pragma unroll
                     for (int k = 0; k < 8; ++k) contour -= ln[k];
                     uint32_t out = c8;
-                    if (__ballot(!(contour <= 0.0499f * lin_c)) != 0ull) out = post_pixel_t<true>(s_thresh, s_decode, c8, lin_c, ln, lut, kSrgb);
+                    const bool long_post = __ballot(!(contour <= 0.0499f * lin_c)) != 0ull;
+#ifdef TOPO_RESOLVE_STATS
+                    if (lane == 0) { atomicAdd(&P.counters[table ? 8 : 9], 1u); if (long_post) atomicAdd(&P.counters[10], 1u); }
+#endif
+                    if (long_post) out = post_pixel_t<true>(s_thresh, s_decode, c8, lin_c, ln, lut, kSrgb);
                     if (in_x) *reinterpret_cast<uint32_t*>(rgba_p) = surface_order<kBgra>(out);
                 }
                 TOPO_PROF(6)  // pixels
                 gbase += table ? cnt : 0u;
                 r0 = r1;
             }
+            have = more;
+            j_cur = j_next;
+#ifdef TOPO_RESOLVE_EARLY_PREFETCH
             K = Kn;
+#endif
         }
         while (mc) resolve_fill_sky<kBgra>(P, O, block_of(pop_bit(mc)), lane, wave);
         TOPO_PROF(1)

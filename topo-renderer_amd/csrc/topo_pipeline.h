@@ -741,17 +741,22 @@ TOPO_HD PixelAt pixel_at(int32_t W, int32_t H, int32_t px, int32_t py, int32_t o
     return PixelAt{px, py, (double)(px - ox), (double)(py - oy), pixel_gx(px, div_f(2.0f, (float)W)), pixel_gy(py, div_f(2.0f, (float)H))};
 }
 
-// world_pos.xy and the world normal of the fragment at `at`; false = no varyings (the pixel keeps the cleared colour)
+// world_pos.xy and the world normal of the fragment at `at`; false = no varyings (the pixel keeps the cleared colour).
+// (Evaluating kinds 1 and 3 for every pixel and selecting the weights -- no divergent branch -- measured 3 % slower in
+// k_resolve than the branches: the binary64 forms run at half rate and a third of the c4 near field is kind 3.)
 TOPO_HD bool resolve_pixel(const TriRecord& rec, const PixelAt& at, float& wposx, float& wposy, f3& wnrm) {
-    float q0, q1, q2;
-    if (rec.kind == 1u || rec.kind == 2u) {
-        float f0, f1, f2;
-        if (rec.kind == 1u) {
-            const double F1 = fma(f64_from_words(rec.u0, rec.u1), at.dx, fma(f64_from_words(rec.u2, rec.u3), at.dy, f64_from_words(rec.u4, rec.u5)));
-            const double F2 = fma(f64_from_words(rec.u6, rec.u7), at.dx, fma(f64_from_words(rec.u8, rec.u9), at.dy, f64_from_words(rec.u10, rec.u11)));
-            const double F0 = (f64_from_words(rec.u12, rec.u13) - F1) - F2;
-            f0 = (float)F0; f1 = (float)F1; f2 = (float)F2;
-        } else {
+    const double F1 = fma(f64_from_words(rec.u0, rec.u1), at.dx, fma(f64_from_words(rec.u2, rec.u3), at.dy, f64_from_words(rec.u4, rec.u5)));
+    const double F2 = fma(f64_from_words(rec.u6, rec.u7), at.dx, fma(f64_from_words(rec.u8, rec.u9), at.dy, f64_from_words(rec.u10, rec.u11)));
+    const double F0 = (f64_from_words(rec.u12, rec.u13) - F1) - F2;
+    float f0 = (float)F0, f1 = (float)F1, f2 = (float)F2;
+#ifndef TOPO_PIXEL_UNCONDITIONAL      // (experiment build TOPO_PIXEL_UNCONDITIONAL: kinds 1 and 3 both evaluated and selected -- measured 3 % slower: the f64 forms are half rate)
+    float q0 = 0.0f, q1 = 0.0f, q2 = 0.0f;
+    if (rec.kind == 3u) {
+        q0 = fmaf(bits_f(rec.u0), at.gx, fmaf(bits_f(rec.u1), at.gy, bits_f(rec.u2)));
+        q1 = fmaf(bits_f(rec.u3), at.gx, fmaf(bits_f(rec.u4), at.gy, bits_f(rec.u5)));
+        q2 = fmaf(bits_f(rec.u6), at.gx, fmaf(bits_f(rec.u7), at.gy, bits_f(rec.u8)));
+    } else {
+        if (rec.kind == 2u) {
             const int32_t X0 = (int32_t)rec.u0, X1 = (int32_t)rec.u1, X2 = (int32_t)rec.u2, Y0 = (int32_t)rec.u3, Y1 = (int32_t)rec.u4, Y2 = (int32_t)rec.u5;
             const int32_t cx = at.px * 256 + 128, cy = at.py * 256 + 128;
             f0 = (float)((int64_t)(Y2 - Y1) * (cx - X1) - (int64_t)(X2 - X1) * (cy - Y1));
@@ -760,20 +765,30 @@ TOPO_HD bool resolve_pixel(const TriRecord& rec, const PixelAt& at, float& wposx
         }
         const float iA = bits_f(rec.iA);
         q0 = (f0 * iA) * bits_f(rec.iw0); q1 = (f1 * iA) * bits_f(rec.iw1); q2 = (f2 * iA) * bits_f(rec.iw2);
-    } else if (rec.kind == 3u) {
-        q0 = fmaf(bits_f(rec.u0), at.gx, fmaf(bits_f(rec.u1), at.gy, bits_f(rec.u2)));
-        q1 = fmaf(bits_f(rec.u3), at.gx, fmaf(bits_f(rec.u4), at.gy, bits_f(rec.u5)));
-        q2 = fmaf(bits_f(rec.u6), at.gx, fmaf(bits_f(rec.u7), at.gy, bits_f(rec.u8)));
-    } else {
-        return false;
     }
+#else
+    if (rec.kind == 2u) {
+        const int32_t X0 = (int32_t)rec.u0, X1 = (int32_t)rec.u1, X2 = (int32_t)rec.u2, Y0 = (int32_t)rec.u3, Y1 = (int32_t)rec.u4, Y2 = (int32_t)rec.u5;
+        const int32_t cx = at.px * 256 + 128, cy = at.py * 256 + 128;
+        f0 = (float)((int64_t)(Y2 - Y1) * (cx - X1) - (int64_t)(X2 - X1) * (cy - Y1));
+        f1 = (float)((int64_t)(Y0 - Y2) * (cx - X2) - (int64_t)(X0 - X2) * (cy - Y2));
+        f2 = (float)((int64_t)(Y1 - Y0) * (cx - X0) - (int64_t)(X1 - X0) * (cy - Y0));
+    }
+    const float iA = bits_f(rec.iA);
+    const float a0 = (f0 * iA) * bits_f(rec.iw0), a1 = (f1 * iA) * bits_f(rec.iw1), a2 = (f2 * iA) * bits_f(rec.iw2);
+    const float h0 = fmaf(bits_f(rec.u0), at.gx, fmaf(bits_f(rec.u1), at.gy, bits_f(rec.u2)));
+    const float h1 = fmaf(bits_f(rec.u3), at.gx, fmaf(bits_f(rec.u4), at.gy, bits_f(rec.u5)));
+    const float h2 = fmaf(bits_f(rec.u6), at.gx, fmaf(bits_f(rec.u7), at.gy, bits_f(rec.u8)));
+    const bool cut = rec.kind == 3u;
+    const float q0 = cut ? h0 : a0, q1 = cut ? h1 : a1, q2 = cut ? h2 : a2;
+#endif
     const float iq = div_f(1.0f, (q0 + q1) + q2);
     wposx = fmaf(bits_f(rec.wx2), q2, fmaf(bits_f(rec.wx1), q1, bits_f(rec.wx0) * q0)) * iq;
     wposy = fmaf(bits_f(rec.wy2), q2, fmaf(bits_f(rec.wy1), q1, bits_f(rec.wy0) * q0)) * iq;
     wnrm.x = fmaf(bits_f(rec.n2x), q2, fmaf(bits_f(rec.n1x), q1, bits_f(rec.n0x) * q0)) * iq;
     wnrm.y = fmaf(bits_f(rec.n2y), q2, fmaf(bits_f(rec.n1y), q1, bits_f(rec.n0y) * q0)) * iq;
     wnrm.z = fmaf(bits_f(rec.n2z), q2, fmaf(bits_f(rec.n1z), q1, bits_f(rec.n0z) * q0)) * iq;
-    return true;
+    return rec.kind != 0u;
 }
 
 // ---- overlay pass: line_shader.wgsl + LineRenderer's pipeline state ---------------------------------
