@@ -58,13 +58,13 @@ def main():
     ap.add_argument("--also-pipelined", action="store_true",
                     help="after the timed region, also time the same panoramas with 2 frames in flight (reported under \"pipelined\", never `value`)")
     ap.add_argument("--pitch", type=float, default=0.0, help="camera pitch in radians (reference: positive looks down)")
-    ap.add_argument("--host-path", action="store_true", help="also time topo_render (host outputs, PCIe-inclusive)")
+    ap.add_argument("--no-host-path", action="store_true", help="skip timing topo_render (host outputs, PCIe-inclusive; an extra key, never `value`)")
     ap.add_argument("--no-pmc", action="store_true",
                     help="skip the rocprofv3 --pmc child passes (FETCH_SIZE, WRITE_SIZE, SQ counters) behind roofline.traffic / roofline_valu")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)      # this process IS such a pass: a few frames, no JSON
     args = ap.parse_args()
     if args.pmc_child:
-        args.no_cpu_baseline = args.no_pmc = True
+        args.no_cpu_baseline = args.no_pmc = args.no_host_path = True
 
     import numpy as np
     import torch
@@ -139,13 +139,23 @@ def main():
     my = list(T.panorama.sector_range(rank, world))
     if world > 1:
         depth_frames = 1            # frames in flight run on the contexts' own streams, which the collective would not wait for
-    use_capi_comm = world > 1 and os.environ.get("TOPO_BENCH_COMM", "torch") == "capi"
-    comm = None
+    # N > 1: the exchange behind the C ABI by default (topo_render_panorama: the frame resolved slot by slot, each slot shipped
+    # over RCCL under the next one's resolve); TOPO_BENCH_COMM=torch = one in-place torch.distributed all-gather after the frame
+    use_capi_comm = world > 1 and os.environ.get("TOPO_BENCH_COMM", "capi") == "capi"
+    comm, comm_note = None, None
     if use_capi_comm:
-        # the collective behind the C ABI (RCCL bound by libtopo_hip.so itself): the unique id travels over torch.distributed
-        uid = torch.from_numpy(T.comm_unique_id() if rank == 0 else np.zeros(128, np.uint8)).cuda()
+        # RCCL is bound by libtopo_hip.so itself; the unique id travels over torch.distributed
+        try:
+            uid = torch.from_numpy(T.comm_unique_id() if rank == 0 else np.zeros(128, np.uint8)).cuda()
+            ok = torch.ones(1, device="cuda")
+        except T.TopoError as e:
+            uid, ok, comm_note = torch.zeros(128, dtype=torch.uint8, device="cuda"), torch.zeros(1, device="cuda"), str(e)
         dist.broadcast(uid, 0)
-        comm = T.Comm(rank, world, uid.cpu().numpy(), device=local_rank)
+        dist.broadcast(ok, 0)
+        if ok.item() > 0:
+            comm = T.Comm(rank, world, uid.cpu().numpy(), device=local_rank)
+        else:
+            use_capi_comm = False      # (every rank falls back together)
     # one output set per frame in flight
     r.set_pipeline_depth(depth_frames)
     outs = [(torch.empty((N_SECTORS, PH, SW, 4), dtype=torch.uint8, device="cuda"),
@@ -294,7 +304,12 @@ def main():
                    "frames_in_flight": depth_frames,
                    "sharding": f"azimuth sectors, {per} per GPU in one submission, DEM replicated" +
                                (", one in-place RCCL all-gather of the sector-major RGBA strip per panorama" +
-                                (" through the C ABI (topo_render_panorama)" if use_capi_comm else " (torch.distributed)") if world > 1 else "")},
+                                (" through the C ABI (topo_render_panorama)" if use_capi_comm else " (torch.distributed)") if world > 1 else "")
+                               if not use_capi_comm or world == 1 else
+                               f"azimuth sectors, {per} per GPU in one cull/raster submission, DEM replicated; resolved and exchanged in "
+                               f"{len(T.panorama_slots(world, SW, PH))} slots through the C ABI (topo_render_panorama: grouped ncclSend/ncclRecv of each "
+                               f"slot on a second stream under the next slot's resolve)",
+                   **({"comm_note": comm_note} if comm_note else {})},
         "roofline": roofline,
         "roofline_valu": roofline_valu,
         "per_kernel": per_kernel,
@@ -347,18 +362,35 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(T, np, locs, vlat, vlon, views, SW, PH, args.cpu_threads)
 
-    # ---- the drop-in entry point hands back HOST buffers: its PCIe-inclusive rate (never `value`)
-    if args.host_path and rank == 0 and world == 1:
+    # ---- the drop-in entry point hands back HOST buffers: its PCIe-inclusive rate (never `value`), one sector-sized frame
+    # (RGBA8 + pad_256-pitched depth) per call: into fresh pageable arrays (through the context's pinned staging image) and
+    # into arrays the caller pinned once (topo_pin_host_buffer: direct copies)
+    if rank == 0 and world == 1 and not args.no_host_path:
         r.set_stream(0)
+        r.set_pipeline_depth(1)
         r.update(SW, PH, views[0], T.post_uniforms(SW, PH))
-        r.render(padded_depth=True)
-        t1 = time.perf_counter()
-        for _ in range(3):
-            r.render(padded_depth=True)
-        dt = (time.perf_counter() - t1) / 3
-        out["topo_render_host_path"] = {"mpix_s": round(SW * PH / 1e6 / dt, 1), "ms": round(dt * 1e3, 3),
-                                        "what": f"one {SW}x{PH} frame through topo_render incl. the device-to-host copies of RGBA8 and "
-                                                f"pad_256-pitched depth into pageable memory"}
+        hrgba = np.empty((PH, SW, 4), np.uint8)
+        hdepth = np.zeros((PH, T.pad_256(4 * SW) // 4), np.float32)
+        nbytes = hrgba.nbytes + hdepth.nbytes
+
+        def timed(n=5):
+            r.render_into(hrgba, hdepth)
+            t1 = time.perf_counter()
+            for _ in range(n):
+                r.render_into(hrgba, hdepth)
+            return (time.perf_counter() - t1) / n
+        dt_staged = timed()
+        r.pin_host_buffer(hrgba)
+        r.pin_host_buffer(hdepth)
+        dt_pinned = timed()
+        r.unpin_host_buffer(hrgba)
+        r.unpin_host_buffer(hdepth)
+        out["topo_render_host_path"] = {
+            "what": f"one {SW}x{PH} frame through topo_render: render + device-to-host copies of RGBA8 and pad_256-pitched depth ({round(nbytes / 1e6, 1)} MB)",
+            "pageable": {"ms": round(dt_staged * 1e3, 3), "GBps": round(nbytes / dt_staged / 1e9, 1), "mpix_s": round(SW * PH / 1e6 / dt_staged, 1),
+                         "how": "pinned staging image of the context, slices copied on by host threads"},
+            "pinned_by_caller": {"ms": round(dt_pinned * 1e3, 3), "GBps": round(nbytes / dt_pinned / 1e9, 1), "mpix_s": round(SW * PH / 1e6 / dt_pinned, 1),
+                                 "how": "topo_pin_host_buffer: direct copies"}}
 
     if args.check and rank == 0:
         mine = strip[my[0]:my[0] + per]

@@ -91,6 +91,14 @@ int topo_update(topo_ctx* ctx, uint32_t width, uint32_t height, const topo_unifo
  * Depth32Float rows depth_pitch bytes apart; the reference uses pad_256(4*width) (data/mod.rs:9-11).
  * Host pointers; synchronous. */
 int topo_render(topo_ctx* ctx, uint8_t* rgba_out, size_t rgba_pitch, float* depth_out, size_t depth_pitch);
+/* The way out to host memory.  The reference presents its frame without a read-back and maps the depth buffer only when the
+ * camera moved (render_engine.rs:219-252); a host that asks topo_render for host images gets them at the link's rate if it
+ * pins the buffers it reuses frame after frame (hipHostRegister under the hood; unpin before freeing them):
+ * topo_render then copies straight into them.  Any other buffer is filled through a pinned staging image of the context's
+ * own, slice by slice (the device copies slice k + 1 while host threads move slice k to the caller's rows) -- several times
+ * the rate of a plain copy into pageable memory, below the pinned one.  depth_out == NULL skips the depth copy. */
+int topo_pin_host_buffer(topo_ctx* ctx, void* buffer, size_t bytes);
+int topo_unpin_host_buffer(topo_ctx* ctx, void* buffer);
 
 const char* topo_last_error(topo_ctx* ctx);
 
@@ -123,11 +131,15 @@ int topo_render_views_device(topo_ctx* ctx, uint32_t n_views, const topo_uniform
  * One process per GPU, each with its own topo_ctx over the same tiles (the DEM is replicated: 1.15 GB of 288 GB).  The
  * strip is TOPO_PANORAMA_SECTORS = 8 fixed sectors of sector_w x sector_h (the cameras of topo_panorama_uniforms), stored
  * SECTOR-MAJOR -- uint8 strip[8][sector_h][sector_w][4], float depth[8][sector_h][sector_w] -- so that the share of rank g,
- * sectors [8g/N, 8(g+1)/N), is one contiguous block.  topo_render_panorama renders this rank's sectors in one submission
- * into their place in strip_dev / depth_dev (device pointers, caller-owned, the same size on every rank) and then
- * all-gathers in place over RCCL (xGMI) on the context's stream: after topo_synchronize every rank holds the whole
- * strip, bit-identical for every N.  comm == NULL (or a world of 1): all 8 sectors, no collective.
- * RCCL is bound at run time (dlopen of librccl.so); nothing else in this library needs it.
+ * sectors [8g/N, 8(g+1)/N), is one contiguous block.  topo_render_panorama renders this rank's sectors into their place in
+ * strip_dev / depth_dev (device pointers, caller-owned, the same size on every rank) -- ONE cull / raster submission for all of
+ * them -- and exchanges them over RCCL (xGMI) so that after topo_synchronize every rank holds the whole strip, bit-identical
+ * for every N.  The exchange is overlapped: the frame is resolved in slots (topo_panorama_slots: a sector of the rank's range
+ * and a band of its rows, ~8 MiB of RGBA each, the same plan on every rank), and behind each slot's resolve kernel the slot
+ * is shipped on a second stream -- every rank sends its part to every other rank and receives theirs straight into place
+ * (grouped ncclSend / ncclRecv: all seven xGMI links of a fully connected node carry a slot at once) -- while the next slot
+ * is being resolved; the context's stream waits for the last exchange.  comm == NULL (or a world of 1): all 8 sectors, no
+ * exchange.  RCCL is bound at run time (dlopen of librccl.so); nothing else in this library needs it.
  *
  * Call sequence for N ranks: rank 0 calls topo_comm_unique_id and hands the 128 bytes to the other ranks through the
  * host's own channel (a file, a socket, MPI, ...); every rank calls topo_comm_init(&comm, its_device, id, rank, N)
@@ -143,6 +155,14 @@ int topo_comm_from_nccl(topo_comm** out, void* nccl_comm, int rank, int world);
 void topo_comm_destroy(topo_comm* comm);
 /* The sectors rank `rank` of `world` renders: [*first, *first + *count). */
 void topo_panorama_sector_range(int rank, int world, uint32_t* first, uint32_t* count);
+typedef struct topo_panorama_slot {
+    uint32_t sector;       /* index within the rank's sector range: sector (first + sector) of the strip */
+    uint32_t row0, rows;   /* the band of pixel rows [row0, row0 + rows) of that sector */
+} topo_panorama_slot;
+/* The resolve / exchange slots of one panorama for a world of `world` ranks, in the order every rank goes through them;
+ * writes up to `cap` of them to `out` (nullable) and returns their number.  Slot i of rank g is bytes
+ * [((g * 8 / world + sector) * sector_h + row0) * sector_w * 4, + rows * sector_w * 4) of the strip. */
+uint32_t topo_panorama_slots(int world, uint32_t sector_w, uint32_t sector_h, topo_panorama_slot* out, uint32_t cap);
 int topo_render_panorama(topo_ctx* ctx, topo_comm* comm, const float eye[3], float yaw0, float pitch, uint32_t sector_w,
                          uint32_t sector_h, float sun_theta_deg, float sun_phi_deg, int32_t view_mode, uint8_t* strip_dev,
                          float* depth_dev /* nullable */);
@@ -206,8 +226,9 @@ int topo_set_pipeline_depth(topo_ctx* ctx, int32_t depth);
  * returns TOPO_ERR_CAPACITY, once per such frame; the frames after it are unaffected.  (topo_render, the synchronous
  * entry point, never hands out such a frame: it grows the queue and renders the frame again.) */
 int topo_join(topo_ctx* ctx);
-/* Status of the most recent frame that has been waited for (waits for the frames in flight first):
- * out[0] = status bits (bit 0 big-triangle queue overflowed: handled exactly, slower; bit 1 rare-triangle queue overflowed:
+/* Status bits of the frames that have completed since the previous call (waits for the frames in flight first; the bits
+ * of all of them OR-ed together, so a burst of frames cannot hide an earlier frame's overflow behind a clean last frame; the
+ * call clears them): out[0] = status bits (bit 0 big-triangle queue overflowed: handled exactly, slower; bit 1 rare-triangle queue overflowed:
  * frame incomplete; bit 2 bounds violation, only ever set by the TOPO_BOUNDS_CHECK build libtopo_hip_check.so),
  * out[1] = site tag and out[2], out[3] = low/high word of the offending value of the first bounds violation. */
 int topo_frame_status(topo_ctx* ctx, uint32_t out[4]);
@@ -242,16 +263,6 @@ int topo_set_timing_slots(topo_ctx* ctx, uint32_t slot_mask);
  * overflowed -- triangles dropped, frame incomplete: see topo_join), [3] rare triangles
  * (>= 64 px across or near-clipped), [4] far blocks occlusion-tested, [5] far blocks that survived the test. */
 int topo_get_counters(topo_ctx* ctx, uint32_t out[6]);
-
-/* Test hook: capacities (entries) of the big-triangle and rare-triangle queues; 0 restores the default (4 Mi each,
- * the rare queue growing on demand under topo_render).  Lets the tests drive the overflow paths: a full big queue is
- * handled exactly (slower); a full rare queue of an explicitly set capacity drops triangles and makes the call that waits
- * for the frame fail with TOPO_ERR_CAPACITY.  rare_cap with bit 31 set = "start at (rare_cap & 0x7FFFFFFF) entries and
- * grow on demand", i.e. the default behaviour from a small starting size. */
-int topo_debug_set_queue_caps(topo_ctx* ctx, uint32_t big_cap, uint32_t rare_cap);
-
-/* Test accessor: the tile's Rgba8Unorm normal texture, w*h*4 bytes, host pointer. */
-int topo_read_normals(topo_ctx* ctx, int32_t lat_deg, int32_t lon_deg, uint8_t* out);
 
 /* ---- host-side helpers mirroring the reference's CPU code ---------------------------------------------- */
 
@@ -336,16 +347,6 @@ void topo_change_location_plan(float latitude, float longitude, float range_dist
                                uint32_t request_cap, uint32_t* n_request);
 int topo_change_location(topo_ctx* ctx, float latitude, float longitude, float range_dist, int32_t* request_out,
                          uint32_t request_cap, uint32_t* n_request, uint32_t* n_unloaded);
-
-/* Synthetic COP90-shaped tile for tests and benches (integer-hash fBm): w*h floats. */
-void topo_synth_tile(int32_t lat_deg, int32_t lon_deg, uint32_t w, uint32_t h, uint32_t seed, float* out);
-
-/* GPU unit-test probe: the device sin/cos of the arithmetic spec over n host floats. */
-int topo_probe_sincos(topo_ctx* ctx, const float* x, float* s, float* c, size_t n);
-
-/* GPU unit-test probe: the device forms of the spec's IEEE divisions over n host floats.  kind 0: x / y (general
- * form, operands inside 2^-96 .. 2^96); kind 1: x / 255; kind 2: x / (0.15f - 0.05f); kind 3: sqrt(x) (y ignored for 1..3). */
-int topo_probe_div(topo_ctx* ctx, int32_t kind, const float* x, const float* y, float* out, size_t n);
 
 #ifdef __cplusplus
 }

@@ -4,6 +4,7 @@ import math
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -15,8 +16,11 @@ def declared_symbols(path):
 
 
 def test_every_declared_symbol_is_exported(topo):
-    decl = declared_symbols(topo.HEADER_PATH)
-    assert len(decl) >= 20
+    boundary, hooks = declared_symbols(topo.HEADER_PATH), declared_symbols(topo.TEST_HEADER_PATH)
+    # the test hooks live in their own header: none of them is declared by the boundary header the Rust bindings come from
+    assert not set(boundary) & set(hooks) and {"topo_probe_sincos", "topo_probe_div", "topo_debug_set_queue_caps", "topo_synth_tile"} <= set(hooks)
+    decl = sorted(set(boundary) | set(hooks))
+    assert len(boundary) >= 20
     nm = subprocess.run(["nm", "-D", "--defined-only", topo.LIB_PATH], capture_output=True, text=True, check=True).stdout
     exported = set(re.findall(r" T (topo_[a-z0-9_]+)", nm))
     missing = [s for s in decl if s not in exported]
@@ -242,3 +246,23 @@ def test_rust_bindings_cover_the_header():
     wrapper = open(os.path.join(root, "rust", "topo-hip", "src", "lib.rs")).read()
     used = set(re.findall(r"sys::(topo_[a-z0-9_]+)\(", wrapper))
     assert used <= bound and {"topo_create", "topo_update", "topo_add_terrain", "topo_unload_terrain", "topo_render", "topo_render_panorama"} <= used
+
+
+def test_missing_rccl_is_an_error_not_a_crash(topo):
+    """A host without librccl.so: topo_comm_unique_id and topo_comm_init(world > 1) return TOPO_ERR_HIP with a message
+    (round 2 called dlerror() twice -- the second call returns NULL -- and crashed in std::string); a world of one needs
+    no RCCL at all.  Own process: the library is bound once per process."""
+    code = ("import numpy as np, topo_renderer_amd as T\n"
+            "for f in (lambda: T.comm_unique_id(), lambda: T.Comm(0, 2, np.zeros(128, np.uint8))):\n"
+            "    try:\n"
+            "        f(); print('NOERR')\n"
+            "    except T.TopoError as e:\n"
+            "        print('ERR', e.code, str(e))\n"
+            "c = T.Comm(0, 1); print('WORLD1', c.world)\n")
+    env = dict(os.environ, TOPO_RCCL_LIB="/nonexistent/librccl.so.1", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = out.stdout.strip().split("\n")
+    assert len(lines) == 3 and lines[2] == "WORLD1 1", lines
+    for l in lines[:2]:
+        assert l.startswith(f"ERR {topo.TOPO_ERR_HIP} ") and "librccl.so not found" in l and len(l) > 40, l

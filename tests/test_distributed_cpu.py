@@ -46,6 +46,28 @@ def _worker(rank, world, port, expect_path, out_q):
         T.panorama.gather_sector_major(dist, strip2, rank, world)
         ok = ok and bool(torch.equal(strip2, expect))
         ok = ok and list(mine) == list(T.panorama_sector_range(rank, world))      # the C ABI's split is the same split
+        # topo_render_panorama's overlapped exchange: the frame resolved and shipped slot by slot (the C ABI's own plan,
+        # topo_panorama_slots, for a sector size that yields several bands per sector), every slot a point-to-point exchange
+        # of one band with every other rank, straight into place, in the same order on every rank
+        big_w, big_h = 2048, 4096                                # the plan of the c4 sector: bands of whole block rows, ~8 MiB each
+        plan = T.panorama_slots(world, big_w, big_h)
+        per = 8 // world
+        ok = ok and len(plan) == per * 4 and all(r0 % 32 == 0 for _, r0, _ in plan) and sorted(set(s for s, _, _ in plan)) == list(range(per))
+        ok = ok and all(sum(r for s, _, r in plan if s == k) == big_h for k in range(per)) and T.panorama_slots(1, big_w, big_h) == [(k, 0, big_h) for k in range(8)]
+        os.environ["TOPO_PANORAMA_BAND_BYTES"] = str(sw * 4 * 40)     # the test's own (tiny) sectors, stretched, with a band size that cuts them
+        plan = T.panorama_slots(world, sw, 4 * sh)
+        del os.environ["TOPO_PANORAMA_BAND_BYTES"]
+        ok = ok and len(plan) == per * 4 and [r for _, _, r in plan[:4]] == [32, 32, 32, 32]
+        tall = torch.from_numpy(np.load(expect_path)).repeat(1, 4, 1, 1)          # [8, 4 sh, sw, 4]
+        strip3 = torch.zeros_like(tall)
+        reqs = []
+        for slot in plan:                                        # "resolve" a slot, then ship it while the next one is produced
+            k = mine[0] + slot[0]
+            strip3[k, slot[1]:slot[1] + slot[2]] = tall[k, slot[1]:slot[1] + slot[2]]
+            reqs += T.panorama.exchange_slot(dist, strip3, slot, rank, world)
+        for r in reqs:
+            r.wait()
+        ok = ok and bool(torch.equal(strip3, tall))
         out_q.put((rank, ok, list(mine)))
     finally:
         dist.destroy_process_group()

@@ -3,6 +3,7 @@
 Depth is compared as raw f32 bits (north_star tolerance: 1 ULP -- we hold 0), colour as RGBA8 bytes
 (tolerance: 1 LSB -- we hold 0)."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -1004,6 +1005,18 @@ def test_panorama_and_batch_entry_points(topo, orc):
         assert np.array_equal(strip.cpu().numpy(), ra) and np.array_equal(depth.cpu().numpy().view(np.uint32), da.view(np.uint32))
     o.update(sw, sh, views[3], topo.post_uniforms(sw, sh))
     assert_same_frame((ra[3], da[3]), o.render(), "panorama sector 3")
+    # the slot-by-slot resolve of the N > 1 path (k_resolve over block ranges, one launch per (sector, band of rows)) without
+    # its exchange -- what a one-GPU box can run of it: the same strip, for bands that cut the sectors into several slots
+    os.environ["TOPO_PANORAMA_FORCE_SLOTS"] = "1"
+    os.environ["TOPO_PANORAMA_BAND_BYTES"] = str(sw * 4 * 50)
+    try:
+        assert len(topo.panorama_slots(2, sw, sh)) == 4 * 3       # 160 rows = five block rows of 32 in bands of two
+        strip.zero_(); depth.zero_()
+        g.render_panorama(comm, sc.eye, yaw0, sw, sh, sc.vlon, sc.vlat, strip.data_ptr(), depth.data_ptr())
+        g.synchronize()
+        assert np.array_equal(strip.cpu().numpy(), ra) and np.array_equal(depth.cpu().numpy().view(np.uint32), da.view(np.uint32))
+    finally:
+        del os.environ["TOPO_PANORAMA_FORCE_SLOTS"], os.environ["TOPO_PANORAMA_BAND_BYTES"]
     # batch: 11 viewpoints (one full group of 8 + a partial one), two submissions in flight
     rng = np.random.default_rng(9)
     eyes, yaws, suns = [], [], []
@@ -1105,3 +1118,40 @@ def test_overlay_lines_over_a_rendered_frame(topo, orc, fmt):
     assert np.array_equal(img.cpu().numpy(), b)
     with pytest.raises(topo.TopoError):
         g.overlay_lines(v, ix[:4], a, width)
+
+
+def test_host_outputs_staged_and_pinned(topo, orc):
+    """topo_render's two ways out to host memory -- through the context's pinned staging image (slices moved on by host
+    threads; odd sizes, a padded depth pitch, a row pitch larger than the row) and straight into buffers the caller pinned
+    (topo_pin_host_buffer) -- hand back the same bytes, the oracle's; unpinning a buffer that was never pinned is an error."""
+    sc = Scene(48, 2, 2, eye_dh=80.0)
+    for (W, H) in ((333, 129), (640, 512)):
+        g, o = both(topo, orc, W, H)
+        sc.load(g)
+        sc.load(o)
+        u, pu = sc.uniforms(W, H, 20.0, 12.0, 70.0, 0), topo.post_uniforms(W, H)
+        g.update(W, H, u, pu)
+        o.update(W, H, u, pu)
+        ref = o.render()
+        rgba = np.zeros((H, W + 3, 4), np.uint8)[:, :W]                      # rows 12 bytes further apart than they are long
+        depth = np.full((H, topo.pad_256(4 * W) // 4), -1.0, np.float32)
+        g.render_into(rgba, depth)
+        assert_same_frame((rgba, depth[:, :W]), ref, f"staged {W}x{H}")
+        assert (depth[:, W:] == -1.0).all()                                  # nothing written beyond a row
+        big = np.zeros((H, W, 4), np.uint8)
+        dbig = np.zeros((H, W), np.float32)
+        g.pin_host_buffer(big)
+        g.pin_host_buffer(dbig)
+        g.pin_host_buffer(big)                                               # (again: fine)
+        g.render_into(big, dbig)
+        assert_same_frame((big, dbig), ref, f"pinned {W}x{H}")
+        big[:] = 0
+        g.render_into(big, None)                                             # depth only when asked for
+        assert np.array_equal(big, ref[0])
+        g.unpin_host_buffer(big)
+        g.unpin_host_buffer(dbig)
+        with pytest.raises(topo.TopoError) as e:
+            g.unpin_host_buffer(dbig)
+        assert e.value.code == topo.TOPO_ERR_NOT_FOUND
+        g.render_into(big, dbig)                                             # and the staged route again for the same arrays
+        assert_same_frame((big, dbig), ref, f"staged after unpin {W}x{H}")

@@ -24,6 +24,7 @@ from . import panorama, synth  # noqa: F401  (re-exported)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TOPO_HIP_LIB") or os.path.join(_HERE, "libtopo_hip.so")   # TOPO_HIP_LIB: A/B builds
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "topo_hip.h")
+TEST_HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "topo_hip_test.h")      # test hooks: not part of the boundary
 
 TOPO_OK = 0
 TOPO_ERR_INVALID, TOPO_ERR_UNSUPPORTED, TOPO_ERR_HIP, TOPO_ERR_NOT_FOUND, TOPO_ERR_CAPACITY = -1, -2, -3, -4, -5
@@ -90,6 +91,8 @@ def lib():
             "topo_synchronize": (C.c_int, [vp]),
             "topo_set_normals_lds_rows": (C.c_int, [vp, C.c_int]),
             "topo_debug_set_queue_caps": (C.c_int, [vp, u32, u32]),
+            "topo_pin_host_buffer": (C.c_int, [vp, vp, sz]),
+            "topo_unpin_host_buffer": (C.c_int, [vp, vp]),
             "topo_get_timings": (C.c_int, [vp, vp]),
             "topo_get_timing_history": (C.c_int, [vp, C.c_uint32, vp, vp]),
             "topo_get_counters": (C.c_int, [vp, vp]),
@@ -110,6 +113,7 @@ def lib():
             "topo_comm_from_nccl": (C.c_int, [C.POINTER(vp), vp, C.c_int, C.c_int]),
             "topo_comm_destroy": (None, [vp]),
             "topo_panorama_sector_range": (None, [C.c_int, C.c_int, vp, vp]),
+            "topo_panorama_slots": (u32, [C.c_int, u32, u32, vp, u32]),
             "topo_render_panorama": (C.c_int, [vp, vp, vp, f32, f32, u32, u32, f32, f32, i32, vp, vp]),
             "topo_render_batch": (C.c_int, [vp, u32, vp, vp, vp, f32, u32, u32, i32, vp, vp]),
             "topo_visible_peaks": (C.c_int, [vp, u32, vp, vp, vp]),
@@ -310,6 +314,14 @@ class Comm:
             pass
 
 
+def panorama_slots(world: int, sector_w: int, sector_h: int):
+    """The resolve / exchange slots of one panorama (topo_panorama_slots): [(sector within the rank's range, row0, rows)]."""
+    n = lib().topo_panorama_slots(world, sector_w, sector_h, None, 0)
+    out = np.zeros((max(1, n), 3), np.uint32)
+    lib().topo_panorama_slots(world, sector_w, sector_h, _p(out), n)
+    return [tuple(int(v) for v in row) for row in out[:n]]
+
+
 def panorama_sector_range(rank: int, world: int):
     a, b = C.c_uint32(), C.c_uint32()
     lib().topo_panorama_sector_range(rank, world, C.byref(a), C.byref(b))
@@ -381,6 +393,18 @@ class TerrainRenderer:
         depth = np.zeros((h, pitch // 4), np.float32)
         self._check(lib().topo_render(self._h, _p(rgba), w * 4, _p(depth), pitch))
         return rgba, (depth if padded_depth else depth[:, :w])
+
+    def render_into(self, rgba: np.ndarray, depth: np.ndarray = None):
+        """topo_render into caller-owned arrays (rgba (h, w, 4) u8; depth (h, pitch / 4) f32 or None) -- the arrays a caller
+        reuses frame after frame and may have pinned (pin_host_buffer)."""
+        self._check(lib().topo_render(self._h, _p(rgba), rgba.strides[0], _p(depth) if depth is not None else None,
+                                      depth.strides[0] if depth is not None else 0))
+
+    def pin_host_buffer(self, a: np.ndarray):
+        self._check(lib().topo_pin_host_buffer(self._h, _p(a), a.nbytes))
+
+    def unpin_host_buffer(self, a: np.ndarray):
+        self._check(lib().topo_unpin_host_buffer(self._h, _p(a)))
 
     def decode_geotiff(self, data: bytes) -> np.ndarray:
         """The f32 raster of a GeoTIFF's first image (topo_geotiff_decode: host container work, GPU predictor/layout)."""

@@ -97,6 +97,10 @@ TerrainRenderer::~TerrainRenderer() {
     for (auto& e : view_ev_)
         if (e) (void)hipEventDestroy(e);
     if (h_views_) (void)hipHostFree(h_views_);
+    if (h_stage_) (void)hipHostFree(h_stage_);
+    for (auto& e : stage_ev_)
+        if (e) (void)hipEventDestroy(e);
+    for (const auto& pin : pinned_) (void)hipHostUnregister(pin.first);
     if (own_stream_) (void)hipStreamDestroy(own_stream_);
 }
 
@@ -344,7 +348,10 @@ bool TerrainRenderer::fold_frames(FrameCtx& c) {
     bool overflow = false;
     for (; c.checked < c.submitted; ++c.checked) {
         const uint32_t* w = c.h_status + (c.checked % kStatusRing) * 16;
-        last_status_[0] = w[2]; last_status_[1] = w[8]; last_status_[2] = w[9]; last_status_[3] = w[10];
+        // status bits accumulate over the frames folded since the last topo_frame_status (which clears them): a burst of frames
+        // cannot hide an earlier frame's overflow or bounds violation behind a clean last frame
+        last_status_[0] |= w[2];
+        if (w[2] & kStatusBounds) { last_status_[1] = w[8]; last_status_[2] = w[9]; last_status_[3] = w[10]; }
         overflow |= (w[2] & kStatusRareOverflow) != 0;
     }
     return overflow;
@@ -390,7 +397,8 @@ int TerrainRenderer::render_views_device(uint32_t n, const topo_uniforms* views,
 }
 
 int TerrainRenderer::render_frame(FrameCtx& c, hipStream_t stream, uint32_t n, const topo_uniforms* views, uint32_t w, uint32_t h,
-                                  const OutputParams& out) {
+                                  const OutputParams& out, const ResolveSlot* slots, uint32_t n_slots,
+                                  const std::function<int(uint32_t, hipStream_t)>* after_slot) {
     const uint32_t n_tiles = (uint32_t)tiles_.size();
     const uint32_t bxc = n_tiles ? (tile_w_ - 1 + kBCX - 1) / kBCX : 0, byc = n_tiles ? (tile_h_ - 1 + kBCY - 1) / kBCY : 0;
     const size_t pixels = (size_t)n * w * h;
@@ -532,7 +540,20 @@ int TerrainRenderer::render_frame(FrameCtx& c, hipStream_t stream, uint32_t n, c
         launch_raster_big(p, stream);
     }
     if (ev_need & (1u << 7)) TOPO_HIP_TRY(hipEventRecord(ev[7], stream));
-    launch_resolve(p, out, stream);
+    if (n_slots == 0) {
+        p.rblock_first = 0;
+        p.rblock_count = p.rblocks_view * n;
+        launch_resolve(p, out, stream);
+    } else {
+        for (uint32_t i = 0; i < n_slots; ++i) {
+            if ((uint64_t)slots[i].block_first + slots[i].block_count > (uint64_t)p.rblocks_view * n) return fail(TOPO_ERR_INVALID, "resolve slot outside the frame");
+            p.rblock_first = slots[i].block_first;
+            p.rblock_count = slots[i].block_count;
+            launch_resolve(p, out, stream);
+            if (after_slot)
+                if (int rc = (*after_slot)(i, stream)) return rc;
+        }
+    }
     if (ev_need & (1u << 8)) TOPO_HIP_TRY(hipEventRecord(ev[8], stream));
     // this frame's counters (queue fills, status bits), for whoever waits for the frame (check_frames, get_counters)
     TOPO_HIP_TRY(hipMemcpyAsync(c.h_status + (c.submitted % kStatusRing) * 16, c.d_counters, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
@@ -576,7 +597,13 @@ int TerrainRenderer::render(uint8_t* rgba, size_t rgba_pitch, float* depth, size
     // A frame whose rare-triangle queue overflowed is incomplete.  The synchronous entry point does not hand such a frame
     // out: it grows the queue to what the frame asked for and renders it again (an explicit topo_debug_set_queue_caps
     // setting is a test hook and is left alone: then the call fails with TOPO_ERR_CAPACITY).
-    if (int rc = synchronize()) return rc;     // frames queued earlier through the asynchronous entry points report here
+    // Frames queued earlier through the asynchronous entry points are waited for, but an overflow of one of THEM is not this
+    // call's error (the caller could not tell which frame failed, and this frame would go unrendered): it stays pending and
+    // is reported, once, by the next topo_join / topo_synchronize -- the calls that wait for those frames.
+    if (int rc = join()) return rc;
+    TOPO_HIP_TRY(hipStreamSynchronize(stream_));
+    for (auto& fc : ctx_)
+        if (!fc.pending && fc.h_status) overflow_pending_ |= fold_frames(fc);
     for (int attempt = 0;; ++attempt) {
         if (int rc = render_views_device(1, &uniforms_, W_, H_, o)) return rc;
         if (int rc = join()) return rc;       // (pipelined contexts run on their own streams)
@@ -593,13 +620,89 @@ int TerrainRenderer::render(uint8_t* rgba, size_t rgba_pitch, float* depth, size
         rare_cap_auto_ = (uint64_t)wanted + wanted / 4u + 1024u;      // the overflowed frame counted what it needs
         if (rare_cap_auto_ > (1ull << 28)) return fail(TOPO_ERR_CAPACITY, "rare-triangle queue would exceed 2^28 entries");
     }
-    TOPO_HIP_TRY(hipMemcpy2DAsync(rgba, rgba_pitch, d_out_rgba_, row, row, H_, hipMemcpyDeviceToHost, stream_));
-    if (depth) TOPO_HIP_TRY(hipMemcpy2DAsync(depth, depth_pitch, d_out_depth_, row, row, H_, hipMemcpyDeviceToHost, stream_));
-    TOPO_HIP_TRY(hipStreamSynchronize(stream_));
+    if (int rc = download(rgba, rgba_pitch, (const uint8_t*)d_out_rgba_, row)) return rc;
+    if (depth)
+        if (int rc = download((uint8_t*)depth, depth_pitch, (const uint8_t*)d_out_depth_, row)) return rc;
     have_depth_ = depth != nullptr;
     depth_w_ = W_;
     depth_h_ = H_;
     return TOPO_OK;
+}
+
+// One H_-row image from device memory into the caller's HOST buffer.  A copy into pageable memory makes the runtime stage it
+// through its own small pinned buffers, synchronously: ~10 GB/s, 6.8 ms for the RGBA + depth of a 2048 x 4096 frame, fifty
+// times the frame's render time.  So: buffers the caller has pinned (topo_pin_host_buffer) are written directly, at the
+// link's rate; any other buffer is filled through a pinned staging buffer of the context's own, in slices -- the device
+// copies slice k + 1 while a few host threads move slice k on to the caller's rows.
+int TerrainRenderer::download(uint8_t* dst, size_t dst_pitch, const uint8_t* src_dev, size_t row) {
+    const size_t span = dst_pitch * (H_ - 1) + row;
+    for (const auto& pin : pinned_)
+        if (dst >= pin.first && dst + span <= pin.first + pin.second) {
+            TOPO_HIP_TRY(hipMemcpy2DAsync(dst, dst_pitch, src_dev, row, row, H_, hipMemcpyDeviceToHost, stream_));
+            TOPO_HIP_TRY(hipStreamSynchronize(stream_));
+            return TOPO_OK;
+        }
+    const size_t total = row * H_;
+    if (total > cap_stage_) {
+        if (h_stage_) (void)hipHostFree(h_stage_);
+        h_stage_ = nullptr;
+        cap_stage_ = 0;
+        TOPO_HIP_TRY(hipHostMalloc((void**)&h_stage_, total));
+        cap_stage_ = total;
+    }
+    constexpr int kSlices = 8;
+    if (!stage_ev_[0])
+        for (auto& e : stage_ev_) TOPO_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    const uint32_t rows_per = (H_ + kSlices - 1) / kSlices;
+    int n_slices = 0;
+    for (uint32_t r0 = 0; r0 < H_; r0 += rows_per, ++n_slices) {
+        const uint32_t rows = std::min(rows_per, H_ - r0);
+        TOPO_HIP_TRY(hipMemcpyAsync(h_stage_ + (size_t)r0 * row, src_dev + (size_t)r0 * row, (size_t)rows * row, hipMemcpyDeviceToHost, stream_));
+        TOPO_HIP_TRY(hipEventRecord(stage_ev_[n_slices], stream_));
+    }
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int n_threads = (int)std::min<size_t>(std::max(1u, std::min(hw ? hw : 4u, 8u)), std::max<size_t>(1, total >> 20));      // one per MiB, at most 8
+    std::atomic<int> failed{0};
+    auto worker = [&](int t) {
+        (void)hipSetDevice(device_);
+        for (int k = 0; k < n_slices; ++k) {
+            if (hipEventSynchronize(stage_ev_[k]) != hipSuccess) { failed = 1; return; }
+            const uint32_t r0 = (uint32_t)k * rows_per, rows = std::min(rows_per, H_ - r0);
+            const uint32_t a = r0 + (uint32_t)((uint64_t)rows * t / n_threads), b = r0 + (uint32_t)((uint64_t)rows * (t + 1) / n_threads);
+            if (dst_pitch == row) memcpy(dst + (size_t)a * row, h_stage_ + (size_t)a * row, (size_t)(b - a) * row);
+            else
+                for (uint32_t r = a; r < b; ++r) memcpy(dst + (size_t)r * dst_pitch, h_stage_ + (size_t)r * row, row);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < n_threads; ++t) pool.emplace_back(worker, t);
+    worker(0);
+    for (auto& th : pool) th.join();
+    if (failed) return fail(TOPO_ERR_HIP, "device-to-host copy failed");
+    return TOPO_OK;
+}
+
+// The caller's own output buffers, pinned once (hipHostRegister): topo_render then copies into them directly.
+int TerrainRenderer::pin_host_buffer(void* p, size_t bytes) {
+    if (!p || bytes == 0) return fail(TOPO_ERR_INVALID, "null/empty buffer");
+    if (int rc = bind_device()) return rc;
+    for (const auto& pin : pinned_)
+        if (pin.first == (uint8_t*)p) return pin.second == bytes ? TOPO_OK : fail(TOPO_ERR_INVALID, "buffer already pinned with another size");
+    TOPO_HIP_TRY(hipHostRegister(p, bytes, hipHostRegisterDefault));
+    pinned_.emplace_back((uint8_t*)p, bytes);
+    return TOPO_OK;
+}
+
+int TerrainRenderer::unpin_host_buffer(void* p) {
+    for (size_t i = 0; i < pinned_.size(); ++i)
+        if (pinned_[i].first == (uint8_t*)p) {
+            if (int rc = bind_device()) return rc;
+            TOPO_HIP_TRY(hipStreamSynchronize(stream_));
+            TOPO_HIP_TRY(hipHostUnregister(p));
+            pinned_.erase(pinned_.begin() + (long)i);
+            return TOPO_OK;
+        }
+    return fail(TOPO_ERR_NOT_FOUND, "buffer was not pinned by topo_pin_host_buffer");
 }
 
 // LineRenderer::render (line_renderer.rs:200-212) over an image this context produced: the overlay triangles are drawn
@@ -696,8 +799,12 @@ int TerrainRenderer::join_frames() {
 int TerrainRenderer::frame_status(uint32_t out[4]) {
     if (int rc = join()) return rc;
     TOPO_HIP_TRY(hipStreamSynchronize(stream_));
-    (void)check_frames();       // refreshes last_status_; an overflow is reported through out[0], not as an error of this call
+    // (folds the finished frames into last_status_; an overflow is reported through out[0] here, and stays pending as the error
+    // of the next call that waits for frames)
+    for (auto& fc : ctx_)
+        if (!fc.pending && fc.h_status) overflow_pending_ |= fold_frames(fc);
     for (int i = 0; i < 4; ++i) out[i] = last_status_[i];
+    last_status_[0] = last_status_[1] = last_status_[2] = last_status_[3] = 0;
     return TOPO_OK;
 }
 

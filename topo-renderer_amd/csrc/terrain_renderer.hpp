@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <functional>
 #include <map>
 #include <string>
 #include <tuple>
@@ -51,7 +52,7 @@ class TerrainRenderer {
     int render(uint8_t* rgba, size_t rgba_pitch, float* depth, size_t depth_pitch);
     int render_views_device(uint32_t n, const topo_uniforms* views, uint32_t w, uint32_t h, const OutputParams& out);
     int render_device(uint8_t* rgba_dev, size_t rgba_pitch, float* depth_dev, size_t depth_pitch);
-    int render_panorama(const Comm* comm, const float eye[3], float yaw0, float pitch, uint32_t sector_w, uint32_t sector_h, float sun_theta_deg,
+    int render_panorama(Comm* comm, const float eye[3], float yaw0, float pitch, uint32_t sector_w, uint32_t sector_h, float sun_theta_deg,
                         float sun_phi_deg, int32_t view_mode, uint8_t* strip_dev, float* depth_dev);
     int render_batch(uint32_t n_viewpoints, const float* eyes, const float* yaw0s, const float* sun_theta_phi_deg, float pitch, uint32_t sector_w,
                      uint32_t sector_h, int32_t view_mode, uint8_t* rgba_dev, float* depth_dev);
@@ -69,6 +70,8 @@ class TerrainRenderer {
     int join_frames();          // topo_join: join + the frames' status (TOPO_ERR_CAPACITY for an incomplete frame)
     int set_normals_lds_rows(int rows);
     int set_queue_caps(uint32_t big_cap, uint32_t rare_cap);
+    int pin_host_buffer(void* p, size_t bytes);
+    int unpin_host_buffer(void* p);
     int get_timings(float out[TOPO_TIMING_SLOTS]);
     int get_timing_history(uint32_t n_frames, float* out_ms, uint32_t* n_out);
     int get_counters(uint32_t out[6]);
@@ -161,7 +164,11 @@ class TerrainRenderer {
     bool fold_frames(FrameCtx& c);             // folds the finished, unchecked frames of c into last_status_; true if one overflowed
     bool overflow_pending_ = false;
     int ensure_on(hipStream_t s, void** p, size_t* cap, size_t need);
-    int render_frame(FrameCtx& c, hipStream_t s, uint32_t n, const topo_uniforms* views, uint32_t w, uint32_t h, const OutputParams& out);
+    // slots: the frame resolved in several launches (k_resolve over block ranges), after_slot(i, stream) called behind each --
+    // null / 0: one launch over the whole frame
+    struct ResolveSlot { uint32_t block_first, block_count; };
+    int render_frame(FrameCtx& c, hipStream_t s, uint32_t n, const topo_uniforms* views, uint32_t w, uint32_t h, const OutputParams& out,
+                     const ResolveSlot* slots = nullptr, uint32_t n_slots = 0, const std::function<int(uint32_t, hipStream_t)>* after_slot = nullptr);
     int frame_durations(FrameCtx& c, int ring, float out[7]);
 
     // grow-only device buffers
@@ -171,6 +178,11 @@ class TerrainRenderer {
     void* d_corner_jobs_ = nullptr; size_t cap_corner_jobs_ = 0;
     void* d_out_rgba_ = nullptr; size_t cap_out_rgba_ = 0;
     void* d_out_depth_ = nullptr; size_t cap_out_depth_ = 0;
+    // topo_render's way out to host memory: a pinned staging image and the events of its slices; the buffers the caller pinned
+    uint8_t* h_stage_ = nullptr; size_t cap_stage_ = 0;
+    hipEvent_t stage_ev_[8] = {};
+    std::vector<std::pair<uint8_t*, size_t>> pinned_;
+    int download(uint8_t* dst, size_t dst_pitch, const uint8_t* src_dev, size_t row);
     static constexpr int kViewSlots = 16;
     static constexpr uint32_t kMaxViewsPerSlot = 64;
     ViewDev* h_views_ = nullptr;          // pinned staging ring
@@ -199,6 +211,7 @@ int comm_init(Comm** out, int device, const uint8_t id128[128], int rank, int wo
 int comm_from_nccl(Comm** out, void* nccl_comm, int rank, int world, std::string* err);
 void comm_destroy(Comm* c);
 void panorama_sector_range(int rank, int world, uint32_t* first, uint32_t* count);
+uint32_t panorama_slots(int world, uint32_t sector_w, uint32_t sector_h, topo_panorama_slot* out, uint32_t cap);
 void geometry_transform(float h, float lon_deg, float lat_deg, float out[3]);
 void terrain_rotation(float model_lon_deg, float model_lat_deg, float rot3x3_colmajor[9]);
 uint32_t locations_range(float latitude, float longitude, float range_dist, int32_t* out_lat_lon, uint32_t cap);

@@ -7,6 +7,7 @@
 #include <utility>
 #include <vector>
 
+#include "../../include/topo_hip_test.h"      // the test hooks are defined here too (their own header: not part of the boundary)
 #include "geotiff.hpp"
 #include "terrain_renderer.hpp"
 
@@ -131,6 +132,16 @@ int topo_get_timings(topo_ctx* ctx, float out_ms[TOPO_TIMING_SLOTS]) {
     TOPO_CALL(ctx->r->get_timings(out_ms));
 }
 
+int topo_pin_host_buffer(topo_ctx* ctx, void* buffer, size_t bytes) {
+    TOPO_GUARD(ctx);
+    TOPO_CALL(ctx->r->pin_host_buffer(buffer, bytes));
+}
+
+int topo_unpin_host_buffer(topo_ctx* ctx, void* buffer) {
+    TOPO_GUARD(ctx);
+    TOPO_CALL(ctx->r->unpin_host_buffer(buffer));
+}
+
 int topo_get_timing_history(topo_ctx* ctx, uint32_t n_frames, float* out_ms, uint32_t* n_out) {
     TOPO_GUARD(ctx);
     if (!n_out) return TOPO_ERR_INVALID;
@@ -235,6 +246,11 @@ void topo_comm_destroy(topo_comm* comm) {
 
 void topo_panorama_sector_range(int rank, int world, uint32_t* first, uint32_t* count) {
     if (first && count && world >= 1 && rank >= 0 && rank < world) topo::panorama_sector_range(rank, world, first, count);
+}
+
+uint32_t topo_panorama_slots(int world, uint32_t sector_w, uint32_t sector_h, topo_panorama_slot* out, uint32_t cap) {
+    if (world < 1 || topo::kPanoramaSectors % (uint32_t)world != 0 || sector_w == 0 || sector_h == 0) return 0;
+    return topo::panorama_slots(world, sector_w, sector_h, out, cap);
 }
 
 int topo_render_panorama(topo_ctx* ctx, topo_comm* comm, const float eye[3], float yaw0, float pitch, uint32_t sector_w, uint32_t sector_h,

@@ -68,7 +68,10 @@ struct FrameParams {
     uint32_t sky_c8;           // the cleared render-target texel (clear colour encoded for the target format), R G B A from the low byte
     uint32_t linear_target;    // 1: plain *Unorm targets (no sRGB encode/decode); 0: *UnormSrgb
     uint32_t bgra;             // 1: output texels are B G R A in memory
-    uint32_t rblocks_x, rblocks_view;             // k_resolve's 64 x 16 px blocks: per row of a view, per view
+    uint32_t rblocks_x, rblocks_view;             // k_resolve's 64 x (4 RPW) px blocks: per row of a view, per view
+    uint32_t rblock_first, rblock_count;          // the blocks THIS launch of k_resolve shades (a frame can be resolved in several
+                                                  // launches -- by view and band of rows -- so that an exchange of the finished part
+                                                  // runs under the rest: topo_render_panorama)
     FastDiv div_rblocks_x, div_rblocks_view;
 };
 

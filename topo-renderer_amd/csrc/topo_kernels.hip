@@ -1184,7 +1184,7 @@ __global__ __launch_bounds__(256, TOPO_RESOLVE_WGS) void k_resolve(FrameParams P
     // part of every view, so each workgroup gets the same mix of sky, far field and near field.  (Handing out runs of
     // consecutive blocks dynamically measured 10 % to 3.5x slower: a run is all sky or all near field, and a block takes
     // ~10 us from first mark to last store, so whoever draws the last near-field run finishes long after everyone else.)
-    const uint32_t n_blocks = P.rblocks_view * P.n_views, stride = gridDim.x;
+    const uint32_t n_blocks = P.rblock_count, stride = gridDim.x;               // blocks P.rblock_first .. of the submission's rblocks_view * n_views
     const uint32_t per_wg = (n_blocks - blockIdx.x + stride - 1) / stride;      // blocks blockIdx.x + j * stride, j < per_wg (the grid is <= n_blocks)
     // once per workgroup: the tables
     s_thresh[threadIdx.x] = threadIdx.x < 255 ? bits_f(TOPO_SRGB_THRESH_BITS[threadIdx.x]) : NAN;
@@ -1216,7 +1216,7 @@ __global__ __launch_bounds__(256, TOPO_RESOLVE_WGS) void k_resolve(FrameParams P
         // ---- which of these blocks' strips hold anything: lane j looks at block j0 + j, all its marks in one trip to memory
         uint64_t mm, mc;       // strips with / without anything drawn
         {
-            const ResolveBlock Bl = resolve_block(P, blockIdx.x + (j0 + (lane < nj ? lane : 0u)) * stride);
+            const ResolveBlock Bl = resolve_block(P, P.rblock_first + blockIdx.x + (j0 + (lane < nj ? lane : 0u)) * stride);
             bool any = false;
 #pragma unroll
             for (uint32_t t = 0; t < kStripMarks; ++t) any |= resolve_strip_marked(P, Bl, wave, t);      // (unconditional loads, none chained to another)
@@ -1226,7 +1226,7 @@ __global__ __launch_bounds__(256, TOPO_RESOLVE_WGS) void k_resolve(FrameParams P
         }
         const uint32_t n_marked = (uint32_t)__popcll(mm), n_clear = (uint32_t)__popcll(mc);
         TOPO_PROF(0)      // marks
-        auto block_of = [&](uint32_t j) { return resolve_block(P, blockIdx.x + (j0 + j) * stride); };      // (j comes out of a wave-uniform mask)
+        auto block_of = [&](uint32_t j) { return resolve_block(P, P.rblock_first + blockIdx.x + (j0 + j) * stride); };      // (j comes out of a wave-uniform mask)
         // the untouched strips are pure stores: spread over the marked strips' iterations, so that their bandwidth hides
         // under the shading
         const uint32_t fills_per_iter = n_marked ? (n_clear + n_marked - 1) / n_marked : n_clear;
@@ -1725,7 +1725,7 @@ void launch_raster_big(const FrameParams& p, hipStream_t s) {
 }
 
 void launch_resolve(const FrameParams& p, const OutputParams& o, hipStream_t s) {
-    const unsigned n_blocks = p.rblocks_view * p.n_views;
+    const unsigned n_blocks = p.rblock_count;
     if (n_blocks == 0) return;
     // four times the resident workgroups: the hardware then hands out workgroups as others finish, which evens out what the
     // static stride leaves uneven (c3: 0.21 -> 0.16 ms; c4, with 128 blocks per resident workgroup, does not care)

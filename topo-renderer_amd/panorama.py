@@ -60,6 +60,24 @@ def gather_sector_major(dist, strip, rank: int, world: int, async_op: bool = Fal
     return dist.all_gather_into_tensor(strip.view(-1), strip[rank * per:(rank + 1) * per].reshape(-1), async_op=async_op)
 
 
+def exchange_slot(dist, strip, slot, rank: int, world: int):
+    """One slot of topo_render_panorama's exchange plan (topo_panorama_slots) on the sector-major strip [8][H][SW][C], with
+    torch.distributed point-to-point operations in the place of the grouped ncclSend / ncclRecv of the C ABI: this rank's
+    band (sector `first + slot.sector`, rows row0 .. row0 + rows) goes to every other rank, theirs come straight into
+    place.  Returns the outstanding requests (wait on all of them before reading the strip)."""
+    if world == 1 or dist is None:
+        return []
+    s, row0, rows = slot
+    per = strip.shape[0] // world
+    ops = []
+    for p in range(world):
+        if p == rank:
+            continue
+        ops.append(dist.P2POp(dist.isend, strip[rank * per + s, row0:row0 + rows], p))
+        ops.append(dist.P2POp(dist.irecv, strip[p * per + s, row0:row0 + rows], p))
+    return dist.batch_isend_irecv(ops)
+
+
 def to_row_major(strip):
     """[per, world, H, SW, C] -> [H, n_sectors*SW, C] (the strip as one image, sectors left to right)."""
     per, world, h, sw = strip.shape[0], strip.shape[1], strip.shape[2], strip.shape[3]
