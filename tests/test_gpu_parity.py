@@ -459,6 +459,18 @@ def test_full_size_config4_sectors_against_oracle(topo, orc):
     ro, do = o.render_views(pick, threads=2)
     for k in range(2):
         assert_same_frame((rg[k], dg[k]), (ro[k], do[k]), f"config-4 sector {k}")
+    # ... and the WHOLE panorama, all eight sectors, against the oracle's bytes: their SHA-256 as committed by
+    # tests/golden/make_c4_hashes.py (the oracle's 16 s per sector paid once, in the build container)
+    import hashlib
+    import json
+    want = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c4_sector_sha256.json")))
+    assert want["sector_w"] == sw and want["sector_h"] == sh and want["n_tiles"] == len(locs)
+    g.set_occlusion_split(90000.0)
+    ra, da = _strip(topo, g, views, sw, sh)
+    for k in range(8):
+        assert hashlib.sha256(np.ascontiguousarray(ra[k]).tobytes()).hexdigest() == want["rgba"][k], f"sector {k}: colour bytes differ from the oracle's"
+        assert hashlib.sha256(np.ascontiguousarray(da[k]).tobytes()).hexdigest() == want["depth"][k], f"sector {k}: depth bits differ from the oracle's"
+    assert hashlib.sha256(np.ascontiguousarray(ro[0]).tobytes()).hexdigest() == want["rgba"][1]      # (the file is the oracle's: sector 1, rendered here)
 
 
 def test_frame_sequence_on_one_renderer(topo, orc):
