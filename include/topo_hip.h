@@ -196,8 +196,7 @@ int topo_visible_peaks_device(topo_ctx* ctx, const topo_uniforms* view, uint32_t
  * (fills) under 100 (the text renderer's layer, text_renderer.rs:291), an equal z keeps the earlier triangle, and z_index
  * <= 1 is never visible.  vs_main: z = z_index / 4096, p = (position + normal * line_width) * (1, -1),
  * clip = (2 p.x / width - 1, 2 p.y / height + 1, z, 1); positions are pixels, y down.  The image is the context's
- * width x height in its colour format (what topo_render / topo_render_device produced).  The glyph rasterisation of the
- * reference's text renderer (glyphon) is a third-party renderer and stays on the host's side. */
+ * width x height in its colour format (what topo_render / topo_render_device produced). */
 typedef struct topo_overlay_vertex {
     float position[2];
     float normal[2];
@@ -209,6 +208,27 @@ int topo_overlay_lines(topo_ctx* ctx, const topo_overlay_vertex* vertices, uint3
                        size_t rgba_pitch);
 int topo_overlay_lines_device(topo_ctx* ctx, const topo_overlay_vertex* vertices, uint32_t n_vertices, const uint32_t* indices,
                               uint32_t n_indices, float line_width, uint8_t* rgba_dev /* device, in/out */, size_t rgba_pitch);
+
+/* TextRenderer::render (text_renderer.rs:198-204, :259-291): the label text, drawn into the same pass after the lines by
+ * glyphon 0.10.0 (third-party; Cargo.lock).  The host keeps what is the host's -- shaping and glyph rasterisation (cosmic-text,
+ * swash) into an R8 mask atlas -- and hands over what glyphon's own vertex buffer holds: one `GlyphToRender` per glyph (28
+ * bytes: quad pos .. pos + dim in pixels showing the atlas texels uv .. uv + dim 1 : 1, color = a << 24 | r << 16 | g << 8 | b,
+ * content_type_with_srgb = {1 = mask atlas, 1 = decode r, g, b from sRGB (ColorMode::Accurate on an *Srgb surface)}).  The
+ * fragment is (color.rgb, color.a * mask) under BlendState::ALPHA_BLENDING -- in linear light on an *Srgb surface -- with the
+ * pass's depth state: Greater with write, every glyph at `depth` (the reference: 100/4096, above the lines), so where quads
+ * overlap the one drawn first keeps its pixels.  Colour glyphs (content type 0) are rejected with TOPO_ERR_UNSUPPORTED. */
+typedef struct topo_glyph {
+    int32_t pos[2];
+    uint16_t dim[2];
+    uint16_t uv[2];
+    uint32_t color;
+    uint16_t content_type_with_srgb[2];
+    float depth;         /* not read: `depth` of the call applies to every glyph */
+} topo_glyph;            /* 28 bytes, = glyphon's GlyphToRender */
+int topo_overlay_glyphs(topo_ctx* ctx, const topo_glyph* glyphs, uint32_t n_glyphs, float depth, const uint8_t* atlas_mask /* host, R8 */,
+                        uint32_t atlas_w, uint32_t atlas_h, uint8_t* rgba /* host, in/out */, size_t rgba_pitch);
+int topo_overlay_glyphs_device(topo_ctx* ctx, const topo_glyph* glyphs /* host */, uint32_t n_glyphs, float depth, const uint8_t* atlas_mask /* host */,
+                               uint32_t atlas_w, uint32_t atlas_h, uint8_t* rgba_dev /* device, in/out */, size_t rgba_pitch);
 
 /* Run the context's work on an existing hipStream_t (e.g. PyTorch's current stream); NULL restores the
  * context's own stream. */

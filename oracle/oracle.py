@@ -174,6 +174,16 @@ class OracleRenderer:
         self._check(L.oracle_overlay_lines(self._h, _p(v), v.nbytes // 32, _p(ix), ix.size, line_width, _p(rgba), rgba.strides[0]))
         return rgba
 
+    def overlay_glyphs(self, glyphs, atlas, rgba, depth=100.0 / 4096.0):
+        """TextRenderer::render over `rgba` (h, w, 4) in place: glyphs = structured/(n, 7) 28-byte GlyphToRender records,
+        atlas (ah, aw) u8 mask."""
+        g = np.ascontiguousarray(glyphs)
+        a = np.ascontiguousarray(atlas, dtype=np.uint8)
+        L = lib()
+        L.oracle_overlay_glyphs.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t]
+        self._check(L.oracle_overlay_glyphs(self._h, _p(g), g.nbytes // 28, depth, _p(a), a.shape[1], a.shape[0], _p(rgba), rgba.strides[0]))
+        return rgba
+
     def render_winners(self):
         """(depth (h,w) f32, winner (h,w) u32): winner = tile rank in draw order * 2(w-1)(h-1) + index-buffer triangle,
         0xFFFFFFFF where nothing was drawn.  Bookkeeping for oracle/ray_check.py."""

@@ -918,6 +918,67 @@ int oracle_overlay_lines(void* p, const void* vertices, uint32_t n_vertices, con
     return 0;
 }
 
+/* ---- overlay pass, text: TextRenderer::render (text_renderer.rs:198-204, :259-291) draws glyphon 0.10.0's glyph quads into
+ * the same post pass after the lines (render_engine.rs:215-216).  glyphon is a third-party crate absent from the tree
+ * (Cargo.lock: glyphon 0.10.0); what is restated here is its published pipeline (src/text_render.rs, src/shader.wgsl):
+ *   - one instance per glyph, `GlyphToRender` (#[repr(C)], 28 bytes): pos [i32; 2] (top-left pixel), dim [u16; 2], uv [u16; 2]
+ *     (top-left atlas texel), color u32 (a << 24 | r << 16 | g << 8 | b), content_type_with_srgb [u16; 2], depth f32;
+ *   - vs_main: the quad pos .. pos + dim in pixels, uv .. uv + dim in atlas texels (1 : 1), z = depth; the colour's r, g, b go
+ *     through the sRGB decode when content_type_with_srgb[1] == 1 (ColorMode::Accurate on an *Srgb surface), a = a8 / 255;
+ *   - fs_main, mask content (content type 1; colour glyphs -- emoji -- are not restated): vec4(color.rgb, color.a * mask)
+ *     with mask = the R8Unorm atlas texel, nearest;
+ *   - blending BlendState::ALPHA_BLENDING: rgb = src.rgb * src.a + dst.rgb * (1 - src.a), a = src.a + dst.a * (1 - src.a),
+ *     in linear light on an *Srgb surface (decode -> blend -> encode);
+ *   - depth: the pass's depth-stencil state, CompareFunction::Greater with write (pipeline.rs:24-32); the reference gives
+ *     every glyph the depth 100 / 4096 (prepare_with_depth(.., |_| 100.0 / 4096.0), text_renderer.rs:291) -- above the post
+ *     quad's 1/4096 and the lines' 2/4096 and 3/4096 -- so of two overlapping quads the one drawn FIRST keeps its pixels,
+ *     transparent ones included (the depth is written wherever the quad covers, whatever the mask says).
+ * `depth` is that one value for the whole call. */
+struct GlyphInst { int32_t pos[2]; uint16_t dim[2], uv[2]; uint32_t color; uint16_t content_type_with_srgb[2]; float depth; };
+static_assert(sizeof(GlyphInst) == 28, "GlyphToRender is 28 bytes");
+
+int oracle_overlay_glyphs(void* p, const void* glyphs, uint32_t n_glyphs, float depth, const uint8_t* atlas, uint32_t aw, uint32_t ah,
+                          uint8_t* rgba, size_t pitch) {
+    Oracle& o = *(Oracle*)p;
+    const GlyphInst* gs = (const GlyphInst*)glyphs;
+    const int64_t W = o.W, H = o.H;
+    std::vector<float> zbuf((size_t)W * H, 1.0f / 4096.0f);
+    const bool is_srgb = format_is_srgb(o.format), bgra = format_is_bgra(o.format);
+    for (uint32_t g = 0; g < n_glyphs; ++g) {
+        const GlyphInst& gi = gs[g];
+        if (gi.content_type_with_srgb[0] != 1) { o.err = "only mask glyphs (content type 1) are restated"; return -1; }
+        const uint32_t c = gi.color;
+        const uint8_t c8[3] = {(uint8_t)(c >> 16), (uint8_t)(c >> 8), (uint8_t)c};
+        float src[3];
+        for (int k = 0; k < 3; ++k) src[k] = gi.content_type_with_srgb[1] == 1 ? srgb().decode[c8[k]] : from_unorm8(c8[k]);
+        const float ca = from_unorm8((uint8_t)(c >> 24));
+        for (int64_t dy = 0; dy < gi.dim[1]; ++dy)
+            for (int64_t dx = 0; dx < gi.dim[0]; ++dx) {
+                const int64_t px = (int64_t)gi.pos[0] + dx, py = (int64_t)gi.pos[1] + dy;
+                if (px < 0 || py < 0 || px >= W || py >= H) continue;
+                const size_t pix = (size_t)py * W + (size_t)px;
+                if (!(depth > zbuf[pix])) continue;      /* CompareFunction::Greater */
+                zbuf[pix] = depth;
+                const uint32_t ax = gi.uv[0] + (uint32_t)dx, ay = gi.uv[1] + (uint32_t)dy;
+                const float mask = ax < aw && ay < ah ? from_unorm8(atlas[(size_t)ay * aw + ax]) : 0.0f;      /* (outside the atlas: transparent) */
+                const float sa = ca * mask;
+                uint8_t* out = rgba + (size_t)py * pitch + (size_t)px * 4;
+                uint8_t d8[4] = {out[0], out[1], out[2], out[3]};
+                if (bgra) std::swap(d8[0], d8[2]);
+                uint8_t r8[4];
+                for (int k = 0; k < 3; ++k) {
+                    const float dst = is_srgb ? srgb().decode[d8[k]] : from_unorm8(d8[k]);
+                    const float v = src[k] * sa + dst * (1.0f - sa);
+                    r8[k] = is_srgb ? srgb().encode(v) : unorm8(v);
+                }
+                r8[3] = unorm8(sa + from_unorm8(d8[3]) * (1.0f - sa));
+                if (bgra) std::swap(r8[0], r8[2]);
+                out[0] = r8[0]; out[1] = r8[1]; out[2] = r8[2]; out[3] = r8[3];
+            }
+    }
+    return 0;
+}
+
 int oracle_read_normals(void* p, int32_t lat, int32_t lon, uint8_t* out) {
     Oracle& o = *(Oracle*)p;
     Tile* t = o.find(lat, lon);

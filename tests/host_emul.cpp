@@ -355,4 +355,26 @@ void emul_srgb_tables(float* decode, float* thresh) {
     for (int i = 0; i < 255; ++i) thresh[i] = bits_f(TOPO_SRGB_THRESH_BITS[i]);
 }
 
+
+// the text overlay through the product's header function glyph_blend, sequentially, with the kernels' ownership rule (the
+// first quad over a pixel keeps it: max of depth << 32 | ~index at one depth per call)
+void emul_overlay_glyphs(const void* glyphs, uint32_t n_glyphs, const uint8_t* atlas, uint32_t aw, uint32_t ah, int W, int H, int srgb, int bgra,
+                         uint8_t* rgba, size_t pitch) {
+    const GlyphInstance* gs = (const GlyphInstance*)glyphs;
+    float thresh[256], decode[256];
+    for (int i = 0; i < 256; ++i) { thresh[i] = bits_f(TOPO_SRGB_THRESH_BITS[i]); decode[i] = bits_f(TOPO_SRGB_DECODE_BITS[i]); }
+    std::vector<uint32_t> owner((size_t)W * H, 0xFFFFFFFFu);
+    for (uint32_t g = 0; g < n_glyphs; ++g)
+        for (uint32_t dy = 0; dy < gs[g].dim[1]; ++dy) for (uint32_t dx = 0; dx < gs[g].dim[0]; ++dx) {
+            const int64_t px = (int64_t)gs[g].pos[0] + dx, py = (int64_t)gs[g].pos[1] + dy;
+            if (px < 0 || py < 0 || px >= W || py >= H) continue;
+            uint32_t& o = owner[(size_t)py * W + px];
+            if (o != 0xFFFFFFFFu) continue;
+            o = g;
+            const uint32_t ax = gs[g].uv[0] + dx, ay = gs[g].uv[1] + dy;
+            const uint32_t mask = ax < aw && ay < ah ? atlas[(size_t)ay * aw + ax] : 0u;
+            uint32_t* out = (uint32_t*)(rgba + (size_t)py * pitch + (size_t)px * 4);
+            *out = glyph_blend(gs[g], mask, *out, srgb != 0, bgra != 0, thresh, decode);
+        }
+}
 }  // extern "C"

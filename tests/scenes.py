@@ -112,3 +112,46 @@ def overlay_geometry(W, H, n_lines=40, n_boxes=12, seed=3):
         idx += [base, base + 1, base + 2, base, base + 2, base + 1]      # both windings: one of them is front-facing
     v = np.array(verts, dtype=OVERLAY_VERTEX)
     return v, np.array(idx, np.uint32)
+
+
+GLYPH = np.dtype([("pos", np.int32, 2), ("dim", np.uint16, 2), ("uv", np.uint16, 2), ("color", np.uint32), ("content_type_with_srgb", np.uint16, 2),
+                  ("depth", np.float32)])      # glyphon 0.10 GlyphToRender, 28 bytes
+
+
+def glyph_scene(W, H, n_labels=14, seed=7):
+    """A mask atlas of synthetic 'glyphs' (antialiased blobs: coverage 0 .. 255) and label-like runs of glyph quads shaped like
+    what the reference's text renderer hands glyphon: rows of small quads advancing to the right, black text (the reference's
+    default colour) and a few coloured / translucent ones, some runs overlapping (the first quad keeps the pixel), some partly
+    or wholly off the target, one glyph whose atlas rectangle sticks out of the atlas."""
+    assert GLYPH.itemsize == 28
+    rng = np.random.default_rng(seed)
+    aw, ah, cell = 96, 64, 16
+    atlas = np.zeros((ah, aw), np.uint8)
+    yy, xx = np.mgrid[0:cell, 0:cell]
+    cells = []
+    for cy in range(ah // cell):
+        for cx in range(aw // cell):
+            gw, gh = int(rng.integers(5, cell)), int(rng.integers(7, cell))
+            c = rng.uniform(2, [gw - 2, gh - 2])
+            r = rng.uniform(2.0, 6.0)
+            cov = np.clip(r - np.hypot(xx - c[0], yy - c[1]) + 0.5, 0, 1) * (xx < gw) * (yy < gh)
+            atlas[cy * cell:(cy + 1) * cell, cx * cell:(cx + 1) * cell] = np.round(255 * cov).astype(np.uint8)
+            cells.append((cx * cell, cy * cell, gw, gh))
+    glyphs = []
+    for i in range(n_labels):
+        x, y = int(rng.integers(-20, W - 10)), int(rng.integers(-10, H - 4))
+        if i % 5 == 4:
+            x, y = glyphs[-1]["pos"][0] - 6, glyphs[-1]["pos"][1] + 3          # a run laid over the previous one
+        color = 0xFF000000 if i % 3 else (int(rng.integers(0, 256)) << 24) | int(rng.integers(0, 1 << 24))
+        for k in range(int(rng.integers(3, 12))):
+            ux, uy, gw, gh = cells[int(rng.integers(0, len(cells)))]
+            g = np.zeros((), GLYPH)
+            g["pos"], g["dim"], g["uv"], g["color"] = (x, y + int(rng.integers(-2, 3))), (gw, gh), (ux, uy), color
+            g["content_type_with_srgb"] = (1, 1 if i % 4 else 0)
+            g["depth"] = 100.0 / 4096.0
+            glyphs.append(g)
+            x += gw + 1
+    g = np.zeros((), GLYPH)                                                      # its atlas rectangle leaves the atlas: transparent there
+    g["pos"], g["dim"], g["uv"], g["color"], g["content_type_with_srgb"], g["depth"] = (W // 2, H // 2), (20, 20), (aw - 8, ah - 8), 0xFF2040FF, (1, 1), 100.0 / 4096.0
+    glyphs.append(g)
+    return np.array(glyphs, dtype=GLYPH), atlas

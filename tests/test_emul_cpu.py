@@ -391,3 +391,22 @@ def test_overlay_pass_header_code_matches_oracle(orc, fmt):
         L.emul_overlay_lines(emul._p(v), len(v), emul._p(ix), ix.size, width, W, H, 1 if fmt in (1, 2) else 0, 1 if fmt in (2, 4) else 0, emul._p(b), W * 4)
         assert np.array_equal(a, b), f"{np.argwhere((a != b).any(axis=-1))[:5]}"
         assert (a != base).any(axis=-1).mean() > 0.05
+
+
+@pytest.mark.parametrize("fmt", [1, 2, 3, 4])
+def test_text_overlay_header_code_matches_oracle(orc, fmt):
+    """The text overlay (glyphon's glyph quads: text_renderer.rs:198-204, :259-291) through the product's header function
+    glyph_blend with the kernels' ownership rule, against the oracle's in-order pass with Greater, in every surface format."""
+    import ctypes as C
+    from scenes import glyph_scene
+    L = emul.lib()
+    L.emul_overlay_glyphs.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+    for W, H, seed in ((200, 120, 1), (97, 61, 2)):
+        glyphs, atlas = glyph_scene(W, H, seed=seed)
+        base = np.random.default_rng(seed).integers(0, 256, (H, W, 4), dtype=np.uint8)
+        a, b = base.copy(), base.copy()
+        orc.OracleRenderer(W, H, color_format=fmt).overlay_glyphs(glyphs, atlas, a)
+        L.emul_overlay_glyphs(emul._p(glyphs), len(glyphs), emul._p(atlas), atlas.shape[1], atlas.shape[0], W, H, 1 if fmt in (1, 2) else 0, 1 if fmt in (2, 4) else 0,
+                              emul._p(b), W * 4)
+        assert np.array_equal(a, b), f"{np.argwhere((a != b).any(axis=-1))[:5]}"
+        assert (a != base).any(axis=-1).mean() > 0.02

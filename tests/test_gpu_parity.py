@@ -1132,6 +1132,52 @@ def test_overlay_lines_over_a_rendered_frame(topo, orc, fmt):
         g.overlay_lines(v, ix[:4], a, width)
 
 
+@pytest.mark.parametrize("fmt", [1, 2, 3])
+def test_text_overlay_over_a_rendered_frame(topo, orc, fmt):
+    """SURVEY 8f rank 4, the text half: glyphon's glyph quads (text_renderer.rs:198-204, :259-291) alpha-blended into the post
+    pass's image after the lines, the first quad over a pixel keeping it -- host entry and device entry, bit-exact against
+    the oracle; lines and text in the reference's order; colour glyphs and a depth at or below the post quad's are refused."""
+    import torch
+    from scenes import glyph_scene, overlay_geometry
+    sc = Scene(64, 2, 2, eye_dh=120.0)
+    W, H = 200, 136
+    g, o = topo.TerrainRenderer(W, H, color_format=fmt), orc.OracleRenderer(W, H, color_format=fmt)
+    sc.load(g)
+    sc.load(o)
+    u, pu = sc.uniforms(W, H, 30, 12, 75, 0), topo.post_uniforms(W, H)
+    g.update(W, H, u, pu)
+    o.update(W, H, u, pu)
+    (rg, _), (ro, _) = g.render(want_depth=False), o.render()
+    assert np.array_equal(rg, ro)
+    v, ix = overlay_geometry(W, H, seed=5)
+    for seed in (3, 4):
+        glyphs, atlas = glyph_scene(W, H, seed=seed)
+        a, b = np.ascontiguousarray(rg.copy()), np.ascontiguousarray(ro.copy())
+        g.overlay_lines(v, ix, a)                       # render_engine.rs:215-216: lines, then text, into the same pass
+        o.overlay_lines(v, ix, b)
+        lines = a.copy()
+        g.overlay_glyphs(glyphs, atlas, a)
+        o.overlay_glyphs(glyphs, atlas, b)
+        assert np.array_equal(a, b), f"format {fmt} seed {seed}: {np.argwhere((a != b).any(axis=-1))[:5]}"
+        assert (a != lines).any(axis=-1).mean() > 0.01
+    img = torch.from_numpy(lines).cuda()
+    g.set_stream(torch.cuda.current_stream().cuda_stream)
+    g.overlay_glyphs_device(glyphs, atlas, img.data_ptr(), W * 4)
+    torch.cuda.synchronize()
+    assert np.array_equal(img.cpu().numpy(), b)
+    g.overlay_glyphs_device(glyphs[:0], atlas, img.data_ptr(), W * 4)      # no glyphs: nothing changes
+    g.overlay_lines_device(v[:0], ix[:0], img.data_ptr(), W * 4)            # and the shared key image was left clean
+    torch.cuda.synchronize()
+    assert np.array_equal(img.cpu().numpy(), b)
+    bad = glyphs[:3].copy()
+    bad["content_type_with_srgb"][1] = (0, 1)
+    with pytest.raises(topo.TopoError) as e:
+        g.overlay_glyphs(bad, atlas, a)
+    assert e.value.code == topo.TOPO_ERR_UNSUPPORTED
+    with pytest.raises(topo.TopoError):
+        g.overlay_glyphs(glyphs, atlas, a, depth=1.0 / 4096.0)
+
+
 def test_host_outputs_staged_and_pinned(topo, orc):
     """topo_render's two ways out to host memory -- through the context's pinned staging image (slices moved on by host
     threads; odd sizes, a padded depth pitch, a row pitch larger than the row) and straight into buffers the caller pinned

@@ -318,3 +318,51 @@ def test_overlay_layering_known_answers(orc):
     assert (over[5, 9, :3] == [255, 0, 0]).all() and (over[11, 9, :3] == [0, 255, 0]).all() and (over[3, 5, :3] == [0, 0, 255]).all()
     same = draw([rect(4, 2, 12, 10, red, 3, flip=flip), rect(4, 2, 12, 10, green, 3, flip=flip)])
     assert (same[5, 9, :3] == [255, 0, 0]).all()                                           # equal depth: the first draw stays
+
+
+def test_text_overlay_known_answers(orc):
+    """glyphon's pipeline as the reference drives it (text_renderer.rs:259-291), on answers that can be worked out by hand:
+    opaque black text replaces the pixel; a zero mask leaves it -- but still owns it: a later quad over the same pixel is
+    rejected by depth Greater at equal depth; half coverage mixes in LINEAR light (decode, mix, encode: the IEC curve in f64);
+    a colour given as sRGB bytes is decoded when the flag says so; the alpha channel follows src.a + dst.a (1 - src.a)."""
+    from scenes import GLYPH
+    W, H = 16, 8
+    atlas = np.zeros((4, 8), np.uint8)
+    atlas[:, 0:2] = 255
+    atlas[:, 2:4] = 128
+    atlas[:, 4:6] = 0
+
+    def glyph(x, y, u, color, srgb=1, w=2, h=2):
+        g = np.zeros((), GLYPH)
+        g["pos"], g["dim"], g["uv"], g["color"], g["content_type_with_srgb"], g["depth"] = (x, y), (w, h), (u, 0), color, (1, srgb), 100 / 4096
+        return g
+    base = np.zeros((H, W, 4), np.uint8)
+    base[...] = (200, 120, 40, 255)
+    gs = np.array([glyph(0, 0, 0, 0xFF000000),              # opaque black
+                   glyph(4, 0, 4, 0xFF000000),              # transparent (mask 0) ...
+                   glyph(4, 0, 0, 0xFFFFFFFF),              # ... but it owns its pixels: this opaque white one is rejected
+                   glyph(8, 0, 2, 0xFF000000),              # mask 128/255 of black
+                   glyph(12, 0, 0, 0xFF8040C0, srgb=1),     # an sRGB colour, opaque
+                   glyph(12, 4, 0, 0xFF8040C0, srgb=0),     # the same bytes taken as linear
+                   glyph(0, 4, 0, 0x80FFFFFF),              # white at alpha 128/255
+                   glyph(14, 6, 0, 0xFF000000, w=4, h=4)],  # partly off the target
+                  dtype=GLYPH)
+    img = orc.OracleRenderer(W, H).overlay_glyphs(gs, atlas, base.copy())
+    enc = lambda l: int(np.floor(255 * (12.92 * l if l <= 0.0031308 else 1.055 * l ** (1 / 2.4) - 0.055) + 0.5))
+    dec = lambda c: (c / 255) / 12.92 if c / 255 <= 0.04045 else ((c / 255 + 0.055) / 1.055) ** 2.4
+    assert (img[0:2, 0:2] == (0, 0, 0, 255)).all()
+    assert (img[0:2, 4:6] == base[0, 0]).all()
+    a = 128 / 255
+    assert tuple(img[0, 8]) == (enc(dec(200) * (1 - a)), enc(dec(120) * (1 - a)), enc(dec(40) * (1 - a)), 255)
+    assert tuple(img[0, 12]) == (0x80, 0x40, 0xC0, 255)                       # decode then encode: the bytes come back
+    assert tuple(img[4, 12]) == (enc(0x80 / 255), enc(0x40 / 255), enc(0xC0 / 255), 255)
+    assert tuple(img[4, 0]) == (enc(a + dec(200) * (1 - a)), enc(a + dec(120) * (1 - a)), enc(a + dec(40) * (1 - a)), 255)
+    assert (img[6:8, 14:16] == (0, 0, 0, 255)).all() and (img[2:4] == base[0, 0]).all()
+    # a destination that is not opaque: alpha = src.a + dst.a (1 - src.a)
+    base2 = base.copy()
+    base2[..., 3] = 100
+    img2 = orc.OracleRenderer(W, H).overlay_glyphs(gs[3:4], atlas, base2)
+    assert img2[0, 8, 3] == int(np.floor(255 * (a + (100 / 255) * (1 - a)) + 0.5))
+    # plain (non-sRGB) surface: no decode, no encode
+    img3 = orc.OracleRenderer(W, H, color_format=3).overlay_glyphs(gs[3:4], atlas, base.copy())
+    assert tuple(img3[0, 8][:3]) == tuple(int(np.floor(c * (1 - a) + 0.5)) for c in (200, 120, 40))

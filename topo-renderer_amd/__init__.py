@@ -106,6 +106,8 @@ def lib():
             "topo_frame_status": (C.c_int, [vp, vp]),
             "topo_overlay_lines": (C.c_int, [vp, vp, u32, vp, u32, f32, vp, sz]),
             "topo_overlay_lines_device": (C.c_int, [vp, vp, u32, vp, u32, f32, vp, sz]),
+            "topo_overlay_glyphs": (C.c_int, [vp, vp, u32, C.c_float, vp, u32, u32, vp, sz]),
+            "topo_overlay_glyphs_device": (C.c_int, [vp, vp, u32, C.c_float, vp, u32, u32, vp, sz]),
             "topo_change_location_plan": (None, [f32, f32, f32, vp, u32, vp, u32, vp, vp, u32, vp]),
             "topo_change_location": (C.c_int, [vp, f32, f32, f32, vp, u32, vp, vp]),
             "topo_comm_unique_id": (C.c_int, [vp]),
@@ -440,6 +442,19 @@ class TerrainRenderer:
         v = np.ascontiguousarray(vertices)
         ix = np.ascontiguousarray(indices, dtype=np.uint32)
         self._check(lib().topo_overlay_lines_device(self._h, _p(v), v.nbytes // 32, _p(ix), ix.size, line_width, C.c_void_p(rgba_ptr), rgba_pitch))
+
+    def overlay_glyphs(self, glyphs, atlas: np.ndarray, rgba: np.ndarray, depth: float = 100.0 / 4096.0) -> np.ndarray:
+        """glyphs: structured array / (n, 7) words of 28-byte GlyphToRender records; atlas (ah, aw) u8 mask; rgba (h, w, 4) u8, in place."""
+        g = np.ascontiguousarray(glyphs)
+        a = np.ascontiguousarray(atlas, dtype=np.uint8)
+        assert rgba.dtype == np.uint8 and rgba.flags.c_contiguous
+        self._check(lib().topo_overlay_glyphs(self._h, _p(g), g.nbytes // 28, depth, _p(a), a.shape[1], a.shape[0], _p(rgba), rgba.strides[0]))
+        return rgba
+
+    def overlay_glyphs_device(self, glyphs, atlas: np.ndarray, rgba_ptr: int, rgba_pitch: int, depth: float = 100.0 / 4096.0):
+        g = np.ascontiguousarray(glyphs)
+        a = np.ascontiguousarray(atlas, dtype=np.uint8)
+        self._check(lib().topo_overlay_glyphs_device(self._h, _p(g), g.nbytes // 28, depth, _p(a), a.shape[1], a.shape[0], C.c_void_p(rgba_ptr), rgba_pitch))
 
     def change_location(self, latitude: float, longitude: float, range_dist: float = 100_000.0):
         """UiController::change_location on this renderer's tile set: unloads what left the range, returns (tiles to fetch, n unloaded)."""

@@ -746,6 +746,49 @@ int TerrainRenderer::overlay_lines(const void* vertices, uint32_t n_vertices, co
     return TOPO_OK;
 }
 
+// TextRenderer::render (text_renderer.rs:198-204) over an image this context produced: glyphon's glyph quads, alpha-blended,
+// the first quad over a pixel keeping it (depth Greater with write at one depth).
+int TerrainRenderer::overlay_glyphs_device(const void* glyphs, uint32_t n_glyphs, float depth, const uint8_t* atlas, uint32_t atlas_w, uint32_t atlas_h,
+                                           uint8_t* rgba_dev, size_t rgba_pitch) {
+    if ((n_glyphs && (!glyphs || !atlas)) || !rgba_dev) return fail(TOPO_ERR_INVALID, "null argument");
+    if (rgba_pitch < (size_t)W_ * 4) return fail(TOPO_ERR_INVALID, "pitch smaller than a row");
+    if (!(depth > 1.0f / 4096.0f) || !(depth <= 1.0f)) return fail(TOPO_ERR_INVALID, "glyph depth must lie above the post quad's 1/4096 (the reference: 100/4096)");
+    const GlyphInstance* gs = (const GlyphInstance*)glyphs;
+    for (uint32_t i = 0; i < n_glyphs; ++i)
+        if (gs[i].content_type_with_srgb[0] != 1) return fail(TOPO_ERR_UNSUPPORTED, "only mask glyphs (glyphon content type 1) are drawn; colour glyphs are not");
+    if (int rc = bind_device()) return rc;
+    const size_t gb = (size_t)n_glyphs * sizeof(GlyphInstance), ab = (size_t)atlas_w * atlas_h, keys_b = (size_t)W_ * H_ * 8;
+    if (int rc = ensure(&d_overlay_geo_, &cap_overlay_geo_, ((gb + 15) & ~(size_t)15) + ab + 16)) return rc;
+    const bool fresh = keys_b > cap_overlay_keys_ || overlay_w_ != W_ || overlay_h_ != H_;
+    if (int rc = ensure(&d_overlay_keys_, &cap_overlay_keys_, keys_b)) return rc;
+    overlay_w_ = W_; overlay_h_ = H_;
+    uint8_t* geo = (uint8_t*)d_overlay_geo_;
+    uint8_t* d_atlas = geo + ((gb + 15) & ~(size_t)15);
+    if (gb) TOPO_HIP_TRY(hipMemcpyAsync(geo, glyphs, gb, hipMemcpyHostToDevice, stream_));
+    if (ab) TOPO_HIP_TRY(hipMemcpyAsync(d_atlas, atlas, ab, hipMemcpyHostToDevice, stream_));
+    const uint32_t linear = (format_ == TOPO_FORMAT_RGBA8_UNORM || format_ == TOPO_FORMAT_BGRA8_UNORM) ? 1u : 0u;
+    const uint32_t bgra = (format_ == TOPO_FORMAT_BGRA8_UNORM_SRGB || format_ == TOPO_FORMAT_BGRA8_UNORM) ? 1u : 0u;
+    launch_overlay_glyphs((const GlyphInstance*)geo, n_glyphs, depth, d_atlas, atlas_w, atlas_h, (int32_t)W_, (int32_t)H_, (uint64_t*)d_overlay_keys_, fresh, rgba_dev,
+                          rgba_pitch, linear, bgra, stream_);
+    TOPO_HIP_TRY(hipStreamSynchronize(stream_));      // glyphs and atlas are only borrowed for the call
+    TOPO_HIP_TRY(hipGetLastError());
+    return TOPO_OK;
+}
+
+int TerrainRenderer::overlay_glyphs(const void* glyphs, uint32_t n_glyphs, float depth, const uint8_t* atlas, uint32_t atlas_w, uint32_t atlas_h, uint8_t* rgba,
+                                    size_t rgba_pitch) {
+    if (!rgba) return fail(TOPO_ERR_INVALID, "null argument");
+    if (rgba_pitch < (size_t)W_ * 4) return fail(TOPO_ERR_INVALID, "pitch smaller than a row");
+    if (int rc = bind_device()) return rc;
+    const size_t row = (size_t)W_ * 4;
+    if (int rc = ensure(&d_out_rgba_, &cap_out_rgba_, row * H_)) return rc;
+    TOPO_HIP_TRY(hipMemcpy2DAsync(d_out_rgba_, row, rgba, rgba_pitch, row, H_, hipMemcpyHostToDevice, stream_));
+    if (int rc = overlay_glyphs_device(glyphs, n_glyphs, depth, atlas, atlas_w, atlas_h, (uint8_t*)d_out_rgba_, row)) return rc;
+    TOPO_HIP_TRY(hipMemcpy2DAsync(rgba, rgba_pitch, d_out_rgba_, row, row, H_, hipMemcpyDeviceToHost, stream_));
+    TOPO_HIP_TRY(hipStreamSynchronize(stream_));
+    return TOPO_OK;
+}
+
 // RenderEngine::get_visible_labels over the depth the context already holds on the device.
 int TerrainRenderer::visible_peaks_device(const topo_uniforms* view, uint32_t w, uint32_t h, const float* depth_dev, size_t depth_pitch,
                                           uint32_t n, const float* peaks_dev, uint8_t* visible_dev, uint32_t* xy_dev) {

@@ -59,6 +59,9 @@ class TerrainRenderer {
     int recompute_normals();
     int overlay_lines_device(const void* vertices, uint32_t n_vertices, const uint32_t* indices, uint32_t n_indices, float line_width, uint8_t* rgba_dev,
                              size_t rgba_pitch);
+    int overlay_glyphs(const void* glyphs, uint32_t n_glyphs, float depth, const uint8_t* atlas, uint32_t atlas_w, uint32_t atlas_h, uint8_t* rgba, size_t rgba_pitch);
+    int overlay_glyphs_device(const void* glyphs, uint32_t n_glyphs, float depth, const uint8_t* atlas, uint32_t atlas_w, uint32_t atlas_h, uint8_t* rgba_dev,
+                              size_t rgba_pitch);
     int overlay_lines(const void* vertices, uint32_t n_vertices, const uint32_t* indices, uint32_t n_indices, float line_width, uint8_t* rgba,
                       size_t rgba_pitch);
     int change_location(float latitude, float longitude, float range_dist, std::vector<std::pair<int32_t, int32_t>>& request, uint32_t* n_unloaded);

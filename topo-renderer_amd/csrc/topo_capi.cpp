@@ -308,6 +308,18 @@ int topo_overlay_lines_device(topo_ctx* ctx, const topo_overlay_vertex* vertices
     TOPO_CALL(ctx->r->overlay_lines_device(vertices, n_vertices, indices, n_indices, line_width, rgba_dev, rgba_pitch));
 }
 
+int topo_overlay_glyphs(topo_ctx* ctx, const topo_glyph* glyphs, uint32_t n_glyphs, float depth, const uint8_t* atlas_mask, uint32_t atlas_w, uint32_t atlas_h,
+                        uint8_t* rgba, size_t rgba_pitch) {
+    TOPO_GUARD(ctx);
+    TOPO_CALL(ctx->r->overlay_glyphs(glyphs, n_glyphs, depth, atlas_mask, atlas_w, atlas_h, rgba, rgba_pitch));
+}
+
+int topo_overlay_glyphs_device(topo_ctx* ctx, const topo_glyph* glyphs, uint32_t n_glyphs, float depth, const uint8_t* atlas_mask, uint32_t atlas_w,
+                               uint32_t atlas_h, uint8_t* rgba_dev, size_t rgba_pitch) {
+    TOPO_GUARD(ctx);
+    TOPO_CALL(ctx->r->overlay_glyphs_device(glyphs, n_glyphs, depth, atlas_mask, atlas_w, atlas_h, rgba_dev, rgba_pitch));
+}
+
 int topo_frame_status(topo_ctx* ctx, uint32_t out[4]) {
     TOPO_GUARD(ctx);
     if (!out) return TOPO_ERR_INVALID;

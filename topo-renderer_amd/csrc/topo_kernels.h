@@ -123,6 +123,8 @@ void launch_overlay(const OverlayVertex* verts, const uint32_t* idx, uint32_t n_
                     bool keys_fresh, uint8_t* rgba, size_t pitch, uint32_t linear_target, uint32_t bgra, hipStream_t s);
 
 // depth consumer (RenderEngine::get_visible_labels, render_engine.rs:338-396)
+void launch_overlay_glyphs(const GlyphInstance* glyphs, uint32_t n_glyphs, float depth, const uint8_t* atlas, uint32_t aw, uint32_t ah, int32_t W, int32_t H,
+                           uint64_t* keys, bool keys_fresh, uint8_t* rgba, size_t pitch, uint32_t linear_target, uint32_t bgra, hipStream_t s);
 void launch_visible_peaks(const float* proj16_dev, uint32_t w, uint32_t h, const float* depth, size_t depth_pitch, uint32_t n,
                           const float* peaks_xyz, uint8_t* visible, uint32_t* xy, hipStream_t s);
 

@@ -1531,6 +1531,51 @@ __global__ __launch_bounds__(256) void k_overlay_resolve(const OverlayVertex* __
     *reinterpret_cast<uint32_t*>(rgba + (size_t)py * pitch + (size_t)px * 4) = out;
 }
 
+// Text: one 64-thread workgroup per glyph quad.  Pass 1 raises the key of every pixel the quad covers (the lines' key image:
+// depth bits << 32 | ~glyph index, 64-bit atomic max = Greater + "the earlier draw keeps an equal depth"); pass 2 lets the
+// glyph that owns a pixel blend into it and puts the key back to the post quad's depth.
+__global__ __launch_bounds__(64) void k_glyph_raster(const GlyphInstance* __restrict__ glyphs, uint32_t n_glyphs, float depth, int32_t W, int32_t H,
+                                                     uint64_t* __restrict__ keys) {
+    const uint32_t g = blockIdx.x;
+    if (g >= n_glyphs) return;
+    const GlyphInstance gi = glyphs[g];
+    const uint32_t gw = gi.dim[0], n = gw * gi.dim[1];
+    const unsigned long long key = (unsigned long long)overlay_key(depth, g);
+    for (uint32_t i = threadIdx.x; i < n; i += 64) {
+        const int64_t px = (int64_t)gi.pos[0] + (int64_t)(i % gw), py = (int64_t)gi.pos[1] + (int64_t)(i / gw);
+        if (px < 0 || py < 0 || px >= W || py >= H) continue;
+        atomicMax(reinterpret_cast<unsigned long long*>(keys + (size_t)py * W + (size_t)px), key);
+    }
+}
+
+__global__ __launch_bounds__(64) void k_glyph_resolve(const GlyphInstance* __restrict__ glyphs, uint32_t n_glyphs, float depth, const uint8_t* __restrict__ atlas,
+                                                      uint32_t aw, uint32_t ah, int32_t W, int32_t H, uint64_t* __restrict__ keys, uint8_t* __restrict__ rgba,
+                                                      size_t pitch, uint32_t linear_target, uint32_t bgra) {
+    __shared__ float s_thresh[256], s_decode[256];
+    for (uint32_t i = threadIdx.x; i < 256; i += 64) {
+        s_thresh[i] = bits_f(TOPO_SRGB_THRESH_BITS[i]);
+        s_decode[i] = bits_f(TOPO_SRGB_DECODE_BITS[i]);
+    }
+    __syncthreads();
+    const uint32_t g = blockIdx.x;
+    if (g >= n_glyphs) return;
+    const GlyphInstance gi = glyphs[g];
+    const uint32_t gw = gi.dim[0], n = gw * gi.dim[1];
+    const uint64_t mine = overlay_key(depth, g);
+    for (uint32_t i = threadIdx.x; i < n; i += 64) {
+        const uint32_t dx = i % gw, dy = i / gw;
+        const int64_t px = (int64_t)gi.pos[0] + dx, py = (int64_t)gi.pos[1] + dy;
+        if (px < 0 || py < 0 || px >= W || py >= H) continue;
+        uint64_t* k = keys + (size_t)py * W + (size_t)px;
+        if (*k != mine) continue;                 // another glyph (an earlier one) owns the pixel, or the depth never passed
+        *k = kOverlayClear;                        // ready for the next overlay call
+        const uint32_t ax = gi.uv[0] + dx, ay = gi.uv[1] + dy;
+        const uint32_t mask = ax < aw && ay < ah ? atlas[(size_t)ay * aw + ax] : 0u;      // (outside the atlas: transparent)
+        uint32_t* out = reinterpret_cast<uint32_t*>(rgba + (size_t)py * pitch + (size_t)px * 4);
+        *out = glyph_blend(gi, mask, *out, linear_target == 0u, bgra != 0u, s_thresh, s_decode);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_overlay_init(uint64_t* __restrict__ keys, size_t n) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) keys[i] = kOverlayClear;
@@ -1746,6 +1791,15 @@ void launch_overlay(const OverlayVertex* verts, const uint32_t* idx, uint32_t n_
     if (n_tris == 0) return;
     hipLaunchKernelGGL(k_overlay_raster, dim3((n_tris + 63) / 64), dim3(64), 0, s, verts, idx, n_tris, n_verts, width, W, H, keys);
     hipLaunchKernelGGL(k_overlay_resolve, dim3((W + 63) / 64, (H + 3) / 4), dim3(256), 0, s, verts, idx, width, W, H, keys, rgba, pitch, linear_target, bgra);
+}
+
+void launch_overlay_glyphs(const GlyphInstance* glyphs, uint32_t n_glyphs, float depth, const uint8_t* atlas, uint32_t aw, uint32_t ah, int32_t W, int32_t H,
+                           uint64_t* keys, bool keys_fresh, uint8_t* rgba, size_t pitch, uint32_t linear_target, uint32_t bgra, hipStream_t s) {
+    const size_t n = (size_t)W * H;
+    if (keys_fresh) hipLaunchKernelGGL(k_overlay_init, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, keys, n);
+    if (n_glyphs == 0) return;
+    hipLaunchKernelGGL(k_glyph_raster, dim3(n_glyphs), dim3(64), 0, s, glyphs, n_glyphs, depth, W, H, keys);
+    hipLaunchKernelGGL(k_glyph_resolve, dim3(n_glyphs), dim3(64), 0, s, glyphs, n_glyphs, depth, atlas, aw, ah, W, H, keys, rgba, pitch, linear_target, bgra);
 }
 
 void launch_visible_peaks(const float* proj16_dev, uint32_t w, uint32_t h, const float* depth, size_t depth_pitch, uint32_t n,

@@ -831,6 +831,41 @@ TOPO_HD bool overlay_color(const OverlayVertex& v0, const OverlayVertex& v1, con
     return true;
 }
 
+// ---- overlay pass, text (text_renderer.rs:198-204, :259-291 over glyphon 0.10.0's pipeline) ---------------------------------
+// glyphon's instance record `GlyphToRender` (#[repr(C)], 28 bytes): the quad pos .. pos + dim (pixels) shows the atlas texels
+// uv .. uv + dim, 1 : 1; color = a << 24 | r << 16 | g << 8 | b; content_type_with_srgb = (1 = mask atlas, 1 = decode the colour's
+// r, g, b from sRGB: ColorMode::Accurate on an *Srgb surface).  Its fragment is (color.rgb, color.a * mask) under
+// BlendState::ALPHA_BLENDING, in linear light on an *Srgb surface; depth test Greater with write at one depth per call
+// (100 / 4096 in the reference), so the FIRST quad over a pixel keeps it.
+struct GlyphInstance {
+    int32_t pos[2];
+    uint16_t dim[2], uv[2];
+    uint32_t color;
+    uint16_t content_type_with_srgb[2];
+    float depth;      // (not read: the call's depth applies to every glyph, as the reference's constant does)
+};
+static_assert(sizeof(GlyphInstance) == 28, "GlyphToRender is 28 bytes");
+// The texel a glyph leaves at a pixel it owns: `dst` = the surface texel in memory order, `mask` = the atlas texel.
+// `decode` = the 256-entry sRGB decode table; encode through the 255 thresholds (srgb_encode).
+TOPO_HD uint32_t glyph_blend(const GlyphInstance& g, uint32_t mask, uint32_t dst, bool srgb_target, bool bgra, const float* thresh, const float* decode) {
+    const uint32_t c = g.color;
+    const uint32_t c8[3] = {(c >> 16) & 255u, (c >> 8) & 255u, c & 255u};
+    const float sa = from_unorm8(c >> 24) * from_unorm8(mask);
+    uint32_t d8[4] = {dst & 255u, (dst >> 8) & 255u, (dst >> 16) & 255u, dst >> 24};
+    if (bgra) { const uint32_t t = d8[0]; d8[0] = d8[2]; d8[2] = t; }
+    uint32_t r8[4];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float src = g.content_type_with_srgb[1] == 1 ? decode[c8[k]] : from_unorm8(c8[k]);
+        const float d = srgb_target ? decode[d8[k]] : from_unorm8(d8[k]);
+        const float v = src * sa + d * (1.0f - sa);
+        r8[k] = srgb_target ? srgb_encode(thresh, v) : to_unorm8(v);
+    }
+    r8[3] = to_unorm8(sa + from_unorm8(d8[3]) * (1.0f - sa));
+    if (bgra) { const uint32_t t = r8[0]; r8[0] = r8[2]; r8[2] = t; }
+    return r8[0] | (r8[1] << 8) | (r8[2] << 16) | (r8[3] << 24);
+}
+
 // ---- peak visibility (render_engine.rs:338-396; glam Mat4::project_point3 + camera.rs:12-14) ---------------
 // This is CPU code in the reference (glam, SSE2: separate multiplies and adds, true divisions), restated as is.
 // Returns true when the peak projects inside the open NDC cube; then (x_pos, y_pos) is its pixel and peak_dist the
