@@ -613,12 +613,50 @@ void draw_tile(Frame& f, const Uniforms& u, const Tile& t, uint32_t draw_base = 
         }
 }
 
+/* The render target as the post pass samples it (s_render: mag Linear, min Nearest, clamp-to-edge, one mip level:
+ * texture.rs:69-78), restated for the pixelise branch (postprocessing_shader.wgsl:70-74), the one place where uv does not
+ * address a texel centre.  What WebGPU leaves to the implementation is fixed as follows (DESIGN.md "Raster spec", item 10):
+ * derivatives are the differences across the pixel's 2 x 2 quad (quads start at even coordinates; a partner pixel outside the
+ * target still has its uv, as a helper invocation has); rho = max(|du/dx| * tw, |dv/dy| * th) (the cross terms are zero: u
+ * depends on x only, v on y only); rho > 1 minifies -- Nearest: texel (floor(u tw), floor(v th)) --, otherwise the sample
+ * magnifies -- Linear: texel coordinates (u tw - 0.5, v th - 0.5), the four texels around them clamped to the edge, decoded,
+ * and weighted with the f32 fractions, mix(mix(c00, c10, fx), mix(c01, c11, fx), fy) with WGSL's mix(a, b, t) = a (1 - t) + b t. */
+static void decode_texel(const Frame& f, int x, int y, float out[4]) {
+    const int W = (int)f.W, H = (int)f.H;
+    x = std::min(std::max(x, 0), W - 1);
+    y = std::min(std::max(y, 0), H - 1);
+    const uint8_t* c8 = &f.color[((size_t)y * W + x) * 4];
+    const bool is_srgb = format_is_srgb(f.format);
+    for (int k = 0; k < 3; ++k) out[k] = is_srgb ? srgb().decode[c8[k]] : from_unorm8(c8[k]);
+    out[3] = from_unorm8(c8[3]);
+}
+static inline float pixelized(float frag, float viewport, float n) { return floorf(frag / viewport * n) / n; }
+static void sample_pixelized(const Frame& f, const PostUniforms& pu, int px, int py, float out[4]) {
+    const float n = pu.pixelize_n, tw = (float)f.W, th = (float)f.H;
+    const float u = pixelized((float)px + 0.5f, pu.viewport[0], n), v = pixelized((float)py + 0.5f, pu.viewport[1], n);
+    const float ux = pixelized((float)(px ^ 1) + 0.5f, pu.viewport[0], n), vy = pixelized((float)(py ^ 1) + 0.5f, pu.viewport[1], n);
+    const float rho = std::max(fabsf(ux - u) * tw, fabsf(vy - v) * th);
+    if (rho > 1.0f) {
+        decode_texel(f, (int)floorf(u * tw), (int)floorf(v * th), out);
+        return;
+    }
+    const float tx = u * tw - 0.5f, ty = v * th - 0.5f;
+    const float x0 = floorf(tx), y0 = floorf(ty), fx = tx - x0, fy = ty - y0;
+    float c00[4], c10[4], c01[4], c11[4];
+    decode_texel(f, (int)x0, (int)y0, c00);
+    decode_texel(f, (int)x0 + 1, (int)y0, c10);
+    decode_texel(f, (int)x0, (int)y0 + 1, c01);
+    decode_texel(f, (int)x0 + 1, (int)y0 + 1, c11);
+    for (int k = 0; k < 4; ++k) out[k] = mix(mix(c00[k], c10[k], fx), mix(c01[k], c11[k], fx), fy);
+}
+
 /* Post pass: postprocessing_shader.wgsl:56-96.  uv = frag.xy / viewport addresses exact texel
  * centres (viewport == target size), so every tap is an exact texel fetch; depth taps clamp to the
- * edge (default sampler: texture.rs:113-117).  pixelize_n >= 99.99999 (always 100 in the reference:
- * application_data.rs:31) -- the pixelise branch is rejected at update(). */
-void post_pass(Frame& f) {
+ * edge (default sampler: texture.rs:113-117).  pixelize_n < 99.99999 (never in the reference, which always passes 100:
+ * application_data.rs:31) moves the COLOUR sample to floor(uv n) / n: sample_pixelized() above. */
+void post_pass(Frame& f, const PostUniforms& pu) {
     const int W = (int)f.W, H = (int)f.H;
+    const bool pixelize = pu.pixelize_n < 99.99999f;
     for (int py = 0; py < H; ++py)
         for (int px = 0; px < W; ++px) {
             const size_t p = (size_t)py * W + px;
@@ -626,6 +664,7 @@ void post_pass(Frame& f) {
             const bool is_srgb = format_is_srgb(f.format);
             float rc[4] = {is_srgb ? srgb().decode[c8[0]] : from_unorm8(c8[0]), is_srgb ? srgb().decode[c8[1]] : from_unorm8(c8[1]),
                            is_srgb ? srgb().decode[c8[2]] : from_unorm8(c8[2]), from_unorm8(c8[3])};
+            if (pixelize) sample_pixelized(f, pu, px, py, rc);
             float center_linear = dist_from_depth(f.depth[p]);
             float contour = 8.0f * center_linear;
             for (int i = -1; i <= 1; ++i)
@@ -674,7 +713,7 @@ void render_frame(const Oracle& o, const Uniforms& u, Frame& f) {
         draw_tile(f, u, *kv.second, rank * 2u * (kv.second->w - 1) * (kv.second->h - 1));
         ++rank;
     }
-    post_pass(f);
+    post_pass(f, o.pu);
 }
 
 void copy_out(const Frame& f, uint8_t* rgba, size_t rgba_pitch, float* depth, size_t depth_pitch,
@@ -749,7 +788,7 @@ int oracle_update(void* p, uint32_t w, uint32_t h, const void* uniforms160, cons
     Oracle& o = *(Oracle*)p;
     PostUniforms pu;
     memcpy(&pu, post16, sizeof pu);
-    if (pu.pixelize_n < 99.99999f) { o.err = "pixelize_n < 99.99999 is not supported"; return -2; }
+    if (pu.pixelize_n < 99.99999f && !(pu.pixelize_n >= 1.0f)) { o.err = "pixelize_n must be at least 1"; return -2; }
     o.W = w; o.H = h;
     memcpy(&o.u, uniforms160, sizeof o.u);
     o.pu = pu;
@@ -841,7 +880,7 @@ int oracle_render_views_tiled(void* p, uint32_t n, const void* uniforms160xn, ui
             std::vector<uint8_t>().swap(q.color);
         }
         f.final_.resize(P * 4);
-        post_pass(f);
+        post_pass(f, o.pu);
         copy_out(f, rgba ? rgba + (size_t)v * rgba_view_stride : nullptr, rgba_pitch,
                  depth ? (float*)((uint8_t*)depth + (size_t)v * depth_view_stride) : nullptr, depth_pitch, nullptr);
     }

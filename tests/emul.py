@@ -83,6 +83,7 @@ class EmulRenderer:
     def update(self, width, height, uniforms, post):
         self.size = (width, height)
         self.u = np.ascontiguousarray(uniforms).view(np.float32).copy()
+        self.post = np.ascontiguousarray(post, dtype=np.float32).copy()
 
     def render(self):
         W, H = self.size
@@ -91,7 +92,10 @@ class EmulRenderer:
         tw, th = (order[0]["h"].shape[1], order[0]["h"].shape[0]) if order else (3, 3)
         rgba = np.empty((H, W, 4), np.uint8)
         depth = np.empty((H, W), np.float32)
+        lib().emul_set_post.argtypes = [C.c_float, C.c_float, C.c_float]
+        lib().emul_set_post(float(self.post[0]), float(self.post[1]), float(self.post[2]))
         rc = lib().emul_render(arr, len(order), tw, th, _p(self.u), W, H, _p(rgba), _p(depth))
+        lib().emul_set_post(0.0, 0.0, 100.0)
         if rc != 0:
             raise RuntimeError("emul_render: winner triangle could not be resolved")
         return rgba, depth

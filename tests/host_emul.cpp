@@ -114,6 +114,8 @@ static void emul_emit(const TriSetup& ts, uint64_t* vis, int W, uint32_t id) {
 
 static int g_split = 0;
 void emul_set_split(int on) { g_split = on; }
+static float g_pixelize[3] = {0.0f, 0.0f, 100.0f};      // PostprocessingUniforms: viewport, pixelize_n (100: the branch off)
+void emul_set_post(float vw, float vh, float n) { g_pixelize[0] = vw; g_pixelize[1] = vh; g_pixelize[2] = n; }
 
 // tiles must be given in draw (BTreeMap) order
 int emul_render(const EmulTile* tiles, uint32_t n_tiles, uint32_t tile_w, uint32_t tile_h, const float* uniforms40,
@@ -197,11 +199,28 @@ int emul_render(const EmulTile* tiles, uint32_t n_tiles, uint32_t tile_w, uint32
         }
         const uint32_t c8 = srgb_encode(thresh, lin[0]) | (srgb_encode(thresh, lin[1]) << 8) | (srgb_encode(thresh, lin[2]) << 16) |
                             (to_unorm8(lin[3]) << 24);
+        memcpy(rgba + ((size_t)py * W + px) * 4, &c8, 4);      // the render target; the post pass below reads it
+        depth[(size_t)py * W + px] = dc;
+    }
+    std::vector<uint32_t> pre((size_t)W * H);
+    memcpy(pre.data(), rgba, (size_t)W * H * 4);
+    const bool pixelize = g_pixelize[2] < 99.99999f;
+    for (int py = 0; py < H; ++py) for (int px = 0; px < W; ++px) {
         float dn[8]; int k = 0;
         for (int i = -1; i <= 1; ++i) for (int j = -1; j <= 1; ++j) { if (i == 0 && j == 0) continue; dn[k++] = linear_depth(vdepth(px + i, py + j)); }
-        const uint32_t o = post_pixel(thresh, decode, c8, linear_depth(dc), dn);
+        const float dc = bits_f((uint32_t)(vis[(size_t)py * W + px] >> 32));
+        uint32_t o;
+        if (pixelize) {
+            float rc[4];
+            sample_pixelized(px, py, g_pixelize[0], g_pixelize[1], g_pixelize[2], W, H, [&](int32_t x, int32_t y, float out[4]) {
+                const uint32_t c = pre[(size_t)y * W + x];
+                out[0] = decode[c & 255u]; out[1] = decode[(c >> 8) & 255u]; out[2] = decode[(c >> 16) & 255u]; out[3] = from_unorm8(c >> 24);
+            }, rc);
+            o = post_mix(thresh, rc, linear_depth(dc), dn, true);
+        } else {
+            o = post_pixel(thresh, decode, pre[(size_t)py * W + px], linear_depth(dc), dn);
+        }
         memcpy(rgba + ((size_t)py * W + px) * 4, &o, 4);
-        depth[(size_t)py * W + px] = dc;
     }
     return 0;
 }

@@ -410,3 +410,36 @@ def test_text_overlay_header_code_matches_oracle(orc, fmt):
                               emul._p(b), W * 4)
         assert np.array_equal(a, b), f"{np.argwhere((a != b).any(axis=-1))[:5]}"
         assert (a != base).any(axis=-1).mean() > 0.02
+
+
+def test_pixelise_branch_header_code_matches_oracle(topo, orc):
+    """The pixelise branch of the post pass (postprocessing_shader.wgsl:70-74) through the product's header functions
+    (sample_pixelized, post_mix) against the oracle, and its sampler's two regimes on a picture where they can be told apart."""
+    for (W, H, n) in ((96, 64, 12.0), (75, 41, 50.0), (64, 48, 3.0)):
+        sc = Scene(24, 2, 2, eye_dh=300.0)
+        e, o = emul.EmulRenderer(W, H, topo.terrain_uniforms), orc.OracleRenderer(W, H)
+        sc.load(e)
+        sc.load(o)
+        u, pu = sc.uniforms(W, H, 25, 20, 70, 0), topo.post_uniforms(W, H, pixelize_n=n)
+        e.update(W, H, u, pu)
+        o.update(W, H, u, pu)
+        assert_same_frame(e.render(), o.render(), f"pixelize_n {n}")
+
+
+def test_pixelise_sampler_known_answers(orc):
+    """The sampler choice of the pixelise branch on a frame whose render target is known: all sky.  Every sample -- Linear
+    or Nearest -- of a constant image is that constant, so the frame equals the unpixelised one; and pixelize_n just under
+    100 still takes the branch while 100 does not (the shader's 99.99999 threshold)."""
+    from scenes import Scene
+    import topo_renderer_amd as T
+    sc = Scene(16, 1, 1, eye_dh=300.0)
+    o = orc.OracleRenderer(48, 32)
+    sc.load(o)
+    up = sc.uniforms(48, 32, 0.0, -80.0, 40.0, 1)
+    o.update(48, 32, up, T.post_uniforms(48, 32))
+    ref = o.render()
+    for n in (1.0, 10.0, 99.9999):
+        o.update(48, 32, up, T.post_uniforms(48, 32, pixelize_n=n))
+        assert_same_frame(o.render(), ref, f"all sky, pixelize_n {n}")
+    with pytest.raises(RuntimeError):
+        o.update(48, 32, up, T.post_uniforms(48, 32, pixelize_n=0.25))

@@ -158,8 +158,42 @@ def test_errors_mirror_reference_limits(topo):
         g.add_terrain(45, 16, np.zeros((20, 20), np.float32), *sc.transform((45, 16)))
     assert e.value.code == topo.TOPO_ERR_INVALID
     with pytest.raises(topo.TopoError) as e:
-        g.update(32, 32, sc.uniforms(32, 32), topo.post_uniforms(32, 32, pixelize_n=50.0))
-    assert e.value.code == topo.TOPO_ERR_UNSUPPORTED
+        g.update(32, 32, sc.uniforms(32, 32), topo.post_uniforms(32, 32, pixelize_n=0.5))
+    assert e.value.code == topo.TOPO_ERR_INVALID
+
+
+@pytest.mark.parametrize("fmt", [1, 2, 3])
+def test_pixelise_branch_of_the_post_pass(topo, orc, fmt):
+    """postprocessing_shader.wgsl:70-74 (never taken by the reference, which pins pixelize_n to 100): the colour sampled at
+    floor(uv n) / n through the render target's sampler -- Linear inside a block of equal uv, Nearest where the pixel's quad
+    straddles two blocks -- then the same contour mix; depth unchanged.  Several block counts, an odd-sized target, a target
+    that is not the viewport's size, with and without a depth output, and back to 100."""
+    import torch
+    sc = Scene(64, 2, 2, eye_dh=120.0)
+    for (W, H, n) in ((200, 136, 50.0), (333, 129, 7.5), (64, 64, 99.0), (128, 96, 1.0)):
+        g, o = topo.TerrainRenderer(W, H, color_format=fmt), orc.OracleRenderer(W, H, color_format=fmt)
+        sc.load(g)
+        sc.load(o)
+        u = sc.uniforms(W, H, 30, 12, 75, 0)
+        plain = topo.post_uniforms(W, H)
+        g.update(W, H, u, plain)
+        ref_plain = g.render()
+        pu = topo.post_uniforms(W, H, pixelize_n=n)
+        g.update(W, H, u, pu)
+        o.update(W, H, u, pu)
+        got, want = g.render(), o.render()
+        assert_same_frame(got, want, f"pixelize_n {n} {W}x{H} format {fmt}")
+        assert np.array_equal(got[1], ref_plain[1]) and (got[0] != ref_plain[0]).any(axis=-1).mean() > 0.05      # same depth, another picture
+        rgba_only, _ = g.render(want_depth=False)
+        assert np.array_equal(rgba_only, want[0])
+        img = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
+        g.set_stream(torch.cuda.current_stream().cuda_stream)
+        g.render_device(img.data_ptr(), W * 4)
+        torch.cuda.synchronize()
+        assert np.array_equal(img.cpu().numpy(), want[0])
+        g.set_stream(0)
+        g.update(W, H, u, plain)
+        assert_same_frame(g.render(), ref_plain, "back to pixelize_n 100")
 
 
 def test_panorama_views_match_per_sector_frames(topo, orc):

@@ -78,7 +78,7 @@ TerrainRenderer::~TerrainRenderer() {
     for (auto& kv : tiles_) {
         (void)hipFree(kv.second.d_pool);
     }
-    void* bufs[] = {d_tiles_, d_views_, d_out_rgba_, d_out_depth_, d_edge_jobs_, d_corner_jobs_, d_peaks_, d_proj_, d_overlay_geo_, d_overlay_keys_};
+    void* bufs[] = {d_tiles_, d_views_, d_out_rgba_, d_out_depth_, d_pre_rgba_, d_pre_depth_, d_edge_jobs_, d_corner_jobs_, d_peaks_, d_proj_, d_overlay_geo_, d_overlay_keys_};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
     for (auto& c : ctx_) {
@@ -295,7 +295,8 @@ int TerrainRenderer::recompute_normals() {
 int TerrainRenderer::update(uint32_t w, uint32_t h, const topo_uniforms* u, const topo_post_uniforms* pu) {
     if (!u || !pu) return fail(TOPO_ERR_INVALID, "null argument");
     if (w == 0 || h == 0) return fail(TOPO_ERR_INVALID, "target size must be non-zero");
-    if (pu->pixelize_n < 99.99999f) return fail(TOPO_ERR_UNSUPPORTED, "pixelize_n < 99.99999 is not supported (the reference always passes 100)");
+    if (pu->pixelize_n < 99.99999f && !(pu->pixelize_n >= 1.0f)) return fail(TOPO_ERR_INVALID, "pixelize_n must be at least 1");
+    if (pu->pixelize_n < 99.99999f && !(pu->viewport[0] >= 1.0f && pu->viewport[1] >= 1.0f)) return fail(TOPO_ERR_INVALID, "viewport must be at least 1 x 1");
     W_ = w;
     H_ = h;
     uniforms_ = *u;
@@ -540,10 +541,30 @@ int TerrainRenderer::render_frame(FrameCtx& c, hipStream_t stream, uint32_t n, c
         launch_raster_big(p, stream);
     }
     if (ev_need & (1u << 7)) TOPO_HIP_TRY(hipEventRecord(ev[7], stream));
+    // The pixelise branch of the post shader (pixelize_n < 99.99999; the reference never takes it) samples the render target
+    // away from the pixel's own texel: k_resolve then stores the render-target texels into an image of the context's
+    // (post_off) and k_post_pixelize makes the surface image from it and the depth image.
+    const bool pixelize = post_.pixelize_n < 99.99999f;
+    OutputParams kout = out;
+    if (pixelize) {
+        if (n_slots) return fail(TOPO_ERR_UNSUPPORTED, "the pixelise branch is not available on the slot-by-slot (multi-GPU) path");
+        const size_t img = (size_t)w * h * 4;
+        if (int rc = ensure_on(stream, &d_pre_rgba_, &cap_pre_rgba_, img * n)) return rc;
+        if (!out.depth)
+            if (int rc = ensure_on(stream, &d_pre_depth_, &cap_pre_depth_, img * n)) return rc;
+        kout.rgba = (uint8_t*)d_pre_rgba_;
+        kout.rgba_view_stride = img;
+        kout.rgba_pitch = (size_t)w * 4;
+        if (!out.depth) { kout.depth = (float*)d_pre_depth_; kout.depth_view_stride = img; kout.depth_pitch = (size_t)w * 4; }
+        p.post_off = 1;
+    }
     if (n_slots == 0) {
         p.rblock_first = 0;
         p.rblock_count = p.rblocks_view * n;
-        launch_resolve(p, out, stream);
+        launch_resolve(p, kout, stream);
+        if (pixelize)
+            launch_post_pixelize(n, (int32_t)w, (int32_t)h, post_.viewport[0] >= 1.0f ? post_.viewport[0] : (float)w, post_.viewport[1] >= 1.0f ? post_.viewport[1] : (float)h,
+                                 post_.pixelize_n, (const uint8_t*)d_pre_rgba_, out, kout.depth, kout.depth_view_stride, kout.depth_pitch, p.linear_target, p.bgra, stream);
     } else {
         for (uint32_t i = 0; i < n_slots; ++i) {
             if ((uint64_t)slots[i].block_first + slots[i].block_count > (uint64_t)p.rblocks_view * n) return fail(TOPO_ERR_INVALID, "resolve slot outside the frame");

@@ -113,7 +113,7 @@ class TerrainRenderer {
     uint32_t format_ = TOPO_FORMAT_RGBA8_UNORM_SRGB;
     uint32_t tile_w_ = 0, tile_h_ = 0;
     topo_uniforms uniforms_{};
-    topo_post_uniforms post_{};
+    topo_post_uniforms post_{{0.0f, 0.0f}, 100.0f, 0.0f};      // (pixelize_n 100: the branch off, as the reference always has it)
     bool have_uniforms_ = false;
     std::map<GeoKey, Tile> tiles_;
     uint64_t next_seq_ = 1;
@@ -181,6 +181,8 @@ class TerrainRenderer {
     void* d_corner_jobs_ = nullptr; size_t cap_corner_jobs_ = 0;
     void* d_out_rgba_ = nullptr; size_t cap_out_rgba_ = 0;
     void* d_out_depth_ = nullptr; size_t cap_out_depth_ = 0;
+    void* d_pre_rgba_ = nullptr; size_t cap_pre_rgba_ = 0;      // the pixelise branch: the render-target image k_post_pixelize samples,
+    void* d_pre_depth_ = nullptr; size_t cap_pre_depth_ = 0;    // and a depth image when the caller wants none
     // topo_render's way out to host memory: a pinned staging image and the events of its slices; the buffers the caller pinned
     uint8_t* h_stage_ = nullptr; size_t cap_stage_ = 0;
     hipEvent_t stage_ev_[8] = {};

@@ -69,6 +69,8 @@ struct FrameParams {
     uint32_t linear_target;    // 1: plain *Unorm targets (no sRGB encode/decode); 0: *UnormSrgb
     uint32_t bgra;             // 1: output texels are B G R A in memory
     uint32_t rblocks_x, rblocks_view;             // k_resolve's 64 x (4 RPW) px blocks: per row of a view, per view
+    uint32_t post_off;         // 1: k_resolve stores the RENDER TARGET texel (no post pass), always R G B A -- the pixelise branch
+                               // samples that image in a pass of its own (k_post_pixelize)
     uint32_t rblock_first, rblock_count;          // the blocks THIS launch of k_resolve shades (a frame can be resolved in several
                                                   // launches -- by view and band of rows -- so that an exchange of the finished part
                                                   // runs under the rest: topo_render_panorama)
@@ -125,6 +127,8 @@ void launch_overlay(const OverlayVertex* verts, const uint32_t* idx, uint32_t n_
 // depth consumer (RenderEngine::get_visible_labels, render_engine.rs:338-396)
 void launch_overlay_glyphs(const GlyphInstance* glyphs, uint32_t n_glyphs, float depth, const uint8_t* atlas, uint32_t aw, uint32_t ah, int32_t W, int32_t H,
                            uint64_t* keys, bool keys_fresh, uint8_t* rgba, size_t pitch, uint32_t linear_target, uint32_t bgra, hipStream_t s);
+void launch_post_pixelize(uint32_t n_views, int32_t W, int32_t H, float vw, float vh, float pixelize_n, const uint8_t* pre_rgba, const OutputParams& out,
+                          const float* depth, size_t depth_view_stride, size_t depth_pitch, uint32_t linear_target, uint32_t bgra, hipStream_t s);
 void launch_visible_peaks(const float* proj16_dev, uint32_t w, uint32_t h, const float* depth, size_t depth_pitch, uint32_t n,
                           const float* peaks_xyz, uint8_t* visible, uint32_t* xy, hipStream_t s);
 

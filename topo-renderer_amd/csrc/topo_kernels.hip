@@ -1437,7 +1437,7 @@ __global__ __launch_bounds__(256, TOPO_RESOLVE_WGS) void k_resolve(FrameParams P
 #pragma unroll
                     for (int k = 0; k < 8; ++k) contour -= ln[k];
                     uint32_t out = c8;
-                    const bool long_post = __ballot(!(contour <= 0.0499f * lin_c)) != 0ull;
+                    const bool long_post = !P.post_off && __ballot(!(contour <= 0.0499f * lin_c)) != 0ull;      // (post_off: the render-target texel itself)
 #ifdef TOPO_RESOLVE_STATS
                     if (lane == 0) { atomicAdd(&P.counters[table ? 8 : 9], 1u); if (long_post) atomicAdd(&P.counters[10], 1u); }
 #endif
@@ -1464,6 +1464,50 @@ __global__ __launch_bounds__(256, TOPO_RESOLVE_WGS) void k_resolve(FrameParams P
     }
 #endif
 #undef TOPO_PROF
+}
+
+// The post pass with the pixelise branch on (postprocessing_shader.wgsl:70-74; never in the reference, which pins pixelize_n to
+// 100): the colour is a sample of the render target AWAY from the pixel's own texel, so the frame takes two passes -- k_resolve
+// stores the render-target texels (post_off), this kernel samples them (sample_pixelized), takes the contour from the depth
+// image and stores the surface texel.  One lane per pixel; nothing here is tuned.
+__global__ __launch_bounds__(256) void k_post_pixelize(int32_t W, int32_t H, float vw, float vh, float n, const uint8_t* __restrict__ pre, OutputParams O,
+                                                       const float* __restrict__ depth, size_t depth_view_stride, size_t depth_pitch, uint32_t linear_target,
+                                                       uint32_t bgra) {
+    __shared__ float s_thresh[256], s_decode[256];
+    s_thresh[threadIdx.x] = bits_f(TOPO_SRGB_THRESH_BITS[threadIdx.x]);
+    s_decode[threadIdx.x] = bits_f(TOPO_SRGB_DECODE_BITS[threadIdx.x]);
+    __syncthreads();
+    const int32_t px = blockIdx.x * 64 + (threadIdx.x & 63), py = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const uint32_t view = blockIdx.z;
+    if (px >= W || py >= H) return;
+    const uint8_t* img = pre + (size_t)view * W * H * 4;
+    const uint8_t* dimg = reinterpret_cast<const uint8_t*>(depth) + (size_t)view * depth_view_stride;
+    auto texel = [&](int32_t x, int32_t y, float out[4]) {
+        const uint32_t c8 = *reinterpret_cast<const uint32_t*>(img + ((size_t)y * W + x) * 4);
+        out[0] = linear_target ? from_unorm8(c8 & 255u) : s_decode[c8 & 255u];
+        out[1] = linear_target ? from_unorm8((c8 >> 8) & 255u) : s_decode[(c8 >> 8) & 255u];
+        out[2] = linear_target ? from_unorm8((c8 >> 16) & 255u) : s_decode[(c8 >> 16) & 255u];
+        out[3] = from_unorm8(c8 >> 24);
+    };
+    float rc[4];
+    sample_pixelized(px, py, vw, vh, n, W, H, texel, rc);
+    auto lin_at = [&](int32_t x, int32_t y) {
+        x = x < 0 ? 0 : (x > W - 1 ? W - 1 : x);
+        y = y < 0 ? 0 : (y > H - 1 ? H - 1 : y);
+        return linear_depth(*reinterpret_cast<const float*>(dimg + (size_t)y * depth_pitch + (size_t)x * 4));
+    };
+    float ln[8];
+    int k = 0;
+#pragma unroll
+    for (int i = -1; i <= 1; ++i)
+#pragma unroll
+        for (int j = -1; j <= 1; ++j) {
+            if (i == 0 && j == 0) continue;
+            ln[k++] = lin_at(px + i, py + j);
+        }
+    uint32_t out = post_mix(s_thresh, rc, lin_at(px, py), ln, linear_target == 0u);
+    if (bgra) out = (out & 0xFF00FF00u) | ((out >> 16) & 0xFFu) | ((out & 0xFFu) << 16);
+    *reinterpret_cast<uint32_t*>(O.rgba + (size_t)view * O.rgba_view_stride + (size_t)py * O.rgba_pitch + (size_t)px * 4) = out;
 }
 
 // ---- overlay pass (line_shader.wgsl) ------------------------------------------------------------------
@@ -1778,9 +1822,10 @@ void launch_resolve(const FrameParams& p, const OutputParams& o, hipStream_t s) 
     unsigned resident = 4u * resident_grid<3>(k_resolve<true, false>, 256 * TOPO_RESOLVE_WGS);
     if (const char* e = getenv("TOPO_RESOLVE_GRID")) resident = (unsigned)atoi(e) ? (unsigned)atoi(e) : n_blocks;      // experiments: 0 = one block per workgroup
     const dim3 grid(n_blocks < resident ? n_blocks : resident), block(256);
-    if (!p.linear_target && !p.bgra) hipLaunchKernelGGL((k_resolve<true, false>), grid, block, 0, s, p, o);
+    const bool bgra = p.bgra && !p.post_off;      // (the render-target image of the pixelise path is always R G B A)
+    if (!p.linear_target && !bgra) hipLaunchKernelGGL((k_resolve<true, false>), grid, block, 0, s, p, o);
     else if (!p.linear_target) hipLaunchKernelGGL((k_resolve<true, true>), grid, block, 0, s, p, o);
-    else if (!p.bgra) hipLaunchKernelGGL((k_resolve<false, false>), grid, block, 0, s, p, o);
+    else if (!bgra) hipLaunchKernelGGL((k_resolve<false, false>), grid, block, 0, s, p, o);
     else hipLaunchKernelGGL((k_resolve<false, true>), grid, block, 0, s, p, o);
 }
 
@@ -1800,6 +1845,12 @@ void launch_overlay_glyphs(const GlyphInstance* glyphs, uint32_t n_glyphs, float
     if (n_glyphs == 0) return;
     hipLaunchKernelGGL(k_glyph_raster, dim3(n_glyphs), dim3(64), 0, s, glyphs, n_glyphs, depth, W, H, keys);
     hipLaunchKernelGGL(k_glyph_resolve, dim3(n_glyphs), dim3(64), 0, s, glyphs, n_glyphs, depth, atlas, aw, ah, W, H, keys, rgba, pitch, linear_target, bgra);
+}
+
+void launch_post_pixelize(uint32_t n_views, int32_t W, int32_t H, float vw, float vh, float pixelize_n, const uint8_t* pre_rgba, const OutputParams& out,
+                          const float* depth, size_t depth_view_stride, size_t depth_pitch, uint32_t linear_target, uint32_t bgra, hipStream_t s) {
+    hipLaunchKernelGGL(k_post_pixelize, dim3((W + 63) / 64, (H + 3) / 4, n_views), dim3(256), 0, s, W, H, vw, vh, pixelize_n, pre_rgba, out, depth, depth_view_stride,
+                       depth_pitch, linear_target, bgra);
 }
 
 void launch_visible_peaks(const float* proj16_dev, uint32_t w, uint32_t h, const float* depth, size_t depth_pitch, uint32_t n,

@@ -382,6 +382,52 @@ TOPO_HD uint32_t post_pixel_t(const float* thresh, const float* decode, uint32_t
     return srgb_encode(thresh, r) | (srgb_encode(thresh, g) << 8) | (srgb_encode(thresh, b) << 16) |
            (to_unorm8(al) << 24);
 }
+// The same mix for a render-target sample that is not a texel (the pixelise branch: a bilinear sample in linear light):
+// rc = the sampled colour (decoded), alpha included.  Returns the surface texel, R G B A from the low byte.
+TOPO_HD uint32_t post_mix(const float* thresh, const float rc[4], float center, const float ln[8], bool srgb_target) {
+    float contour = 8.0f * center;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) contour -= ln[k];
+    const float t = sat(div_const(div_f(contour, center) - 0.05f, 0.15f - 0.05f, 1.0f / (0.15f - 0.05f)));
+    const float a = t * t * (3.0f - 2.0f * t);
+    const float r = rc[0] * (1.0f - a) + 0.0f * a, g = rc[1] * (1.0f - a) + 0.0f * a, b = rc[2] * (1.0f - a) + 0.0f * a;
+    const float al = rc[3] * (1.0f - a) + 1.0f * a;
+    if (!srgb_target) return to_unorm8(r) | (to_unorm8(g) << 8) | (to_unorm8(b) << 16) | (to_unorm8(al) << 24);
+    return srgb_encode(thresh, r) | (srgb_encode(thresh, g) << 8) | (srgb_encode(thresh, b) << 16) | (to_unorm8(al) << 24);
+}
+
+// The pixelise branch of the post shader (postprocessing_shader.wgsl:70-74): uv = floor(uv n) / n, then textureSample of the
+// render target through s_render (mag Linear, min Nearest, clamp-to-edge, one level: texture.rs:69-78).  What WebGPU leaves to
+// the implementation is fixed in DESIGN.md ("Raster spec", item 10): derivatives across the pixel's 2 x 2 quad (quads start at
+// even coordinates), rho = max(|du/dx| tw, |dv/dy| th); rho > 1: the nearest texel (floor(u tw), floor(v th)); otherwise the
+// four texels around (u tw - 1/2, v th - 1/2), clamped to the edge, weighted with the f32 fractions by WGSL's mix.
+// texel(x, y, out): the decoded render-target texel at CLAMPED integer coordinates.
+TOPO_HD float pixelized_uv(float frag, float viewport, float n) { return div_f(floorf(div_f(frag, viewport) * n), n); }      // (n >= 1, viewport >= 1)
+template <typename Texel>
+TOPO_HD void sample_pixelized(int32_t px, int32_t py, float vw, float vh, float n, int32_t tw, int32_t th, Texel&& texel, float out[4]) {
+    const float u = pixelized_uv((float)px + 0.5f, vw, n), v = pixelized_uv((float)py + 0.5f, vh, n);
+    const float ux = pixelized_uv((float)(px ^ 1) + 0.5f, vw, n), vy = pixelized_uv((float)(py ^ 1) + 0.5f, vh, n);
+    const float rx = fabsf(ux - u) * (float)tw, ry = fabsf(vy - v) * (float)th;
+    auto clampi = [](int32_t a, int32_t hi) { return a < 0 ? 0 : (a > hi ? hi : a); };
+    if ((rx > ry ? rx : ry) > 1.0f) {
+        texel(clampi((int32_t)floorf(u * (float)tw), tw - 1), clampi((int32_t)floorf(v * (float)th), th - 1), out);
+        return;
+    }
+    const float tx = u * (float)tw - 0.5f, ty = v * (float)th - 0.5f;
+    const float x0 = floorf(tx), y0 = floorf(ty), fx = tx - x0, fy = ty - y0;
+    const int32_t ix = (int32_t)x0, iy = (int32_t)y0;
+    float c00[4], c10[4], c01[4], c11[4];
+    texel(clampi(ix, tw - 1), clampi(iy, th - 1), c00);
+    texel(clampi(ix + 1, tw - 1), clampi(iy, th - 1), c10);
+    texel(clampi(ix, tw - 1), clampi(iy + 1, th - 1), c01);
+    texel(clampi(ix + 1, tw - 1), clampi(iy + 1, th - 1), c11);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float top = c00[k] * (1.0f - fx) + c10[k] * fx, bot = c01[k] * (1.0f - fx) + c11[k] * fx;
+        out[k] = top * (1.0f - fy) + bot * fy;
+    }
+}
+
 TOPO_HD uint32_t post_pixel(const float* thresh, const float* decode, uint32_t c8, float center, const float ln[8], bool srgb_target = true) {
     return post_pixel_t<false>(thresh, decode, c8, center, ln, nullptr, srgb_target);
 }
