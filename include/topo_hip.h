@@ -253,7 +253,10 @@ int topo_join(topo_ctx* ctx);
  * out[1] = site tag and out[2], out[3] = low/high word of the offending value of the first bounds violation. */
 int topo_frame_status(topo_ctx* ctx, uint32_t out[4]);
 
-/* LDS tile height (output rows per workgroup: 4, 8, 16, 32 or 64) of the interior-normals kernel. */
+/* Form of the interior-normals kernel: 4, 8, 16, 32 or 64 = staged through an LDS tile of that many output rows per
+ * workgroup (BASELINE config 3's sweep knob); 0 (the default: the sweep's optimum on MI355X) = without an LDS tile -- four
+ * texels per lane, the rows above and below kept in registers, neighbours by wave shifts -- for tile widths that are a
+ * multiple of four (other widths take the LDS form with 32 rows).  Same bytes either way. */
 int topo_set_normals_lds_rows(topo_ctx* ctx, int rows);
 
 /* Two-phase occlusion filter: blocks whose nearest possible view depth exceeds `metres` are rastered only if some

@@ -824,6 +824,34 @@ def test_normals_lds_tile_sizes_byte_exact(topo, orc, rows):
         g.set_normals_lds_rows(12)
 
 
+@pytest.mark.parametrize("tile", [152, 260, 516])
+def test_normals_without_lds_byte_exact(topo, orc, tile):
+    """topo_set_normals_lds_rows(0): the interior normals without an LDS tile (k_normals_rolling: four texels per lane, the rows
+    above and below kept in registers, neighbours by DPP wave shifts) against the oracle: tile widths that end inside a strip
+    of 256 columns, exactly on one and beyond two, heights that do not fill the last chunk of rows; add_terrain and the
+    batched recompute; a width that is not a multiple of four falls back to the LDS form."""
+    sc = Scene(tile, 2, 2)
+    g, o = both(topo, orc, 16, 16)
+    g.set_normals_lds_rows(0)
+    sc.load(g)
+    sc.load(o)
+    ref = {loc: o.read_normals(loc[0], loc[1], tile, tile) for loc in sc.locs}
+    for loc in sc.locs:
+        a = g.read_normals(*loc)
+        assert np.array_equal(a, ref[loc]), f"add_terrain tile {loc}: {np.argwhere((a != ref[loc]).any(axis=-1))[:4]}"
+    g.recompute_normals()
+    for loc in sc.locs:
+        assert np.array_equal(g.read_normals(*loc), ref[loc]), f"recompute tile {loc}"
+    if tile == 152:
+        sc2 = Scene(150, 1, 2)
+        g2, o2 = both(topo, orc, 16, 16)
+        g2.set_normals_lds_rows(0)
+        sc2.load(g2)
+        sc2.load(o2)
+        for loc in sc2.locs:
+            assert np.array_equal(g2.read_normals(*loc), o2.read_normals(loc[0], loc[1], 150, 150))
+
+
 def test_config1_single_tile_small_panorama(topo, orc):
     # BASELINE config 1 (the reference's CPU-plumbing case): one 1200x1200 tile, 1024x256 panorama = 8 sectors of 128x256
     sc = Scene(1200, 1, 1, lat0=40, lon0=10, vfrac=(0.623, 0.717))

@@ -415,7 +415,48 @@ static void run_valu() {
     printf("{\"valu_issue_cost\": {%s}, \"unit\": \"cyc_*: s_memtime ticks, ns_*: HIP-event wall time (incl. ~10 us of launch), per wave64 instruction per SIMD\", \"clock_rate_khz\": %d}\n", j.c_str(), clk);
 }
 
+// ---- copy: what a pure read + write stream of the load phase's size reaches on this device (the ceiling k_normals_* is held to)
+typedef float cal_f4 __attribute__((ext_vector_type(4)));
+template <bool kNt>
+__global__ __launch_bounds__(256) void cal_copy16(const cal_f4* __restrict__ in, cal_f4* __restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const cal_f4 v = in[i];
+        if (kNt) __builtin_nontemporal_store(v, out + i);
+        else out[i] = v;
+    }
+}
+static void run_copy() {
+    const size_t bytes = (size_t)576 << 20;      // the c4 DEM: 100 tiles of 1200 x 1200 f32 (and as many bytes of normals out)
+    void *a = nullptr, *b = nullptr;
+    CK(hipMalloc(&a, bytes)); CK(hipMalloc(&b, bytes));
+    CK(hipMemset(a, 1, bytes));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    printf("{\"copy_576MiB\": {");
+    auto run = [&](const char* name, auto kern, unsigned grid, bool last) {
+        float best = 1e9f;
+        for (int r = 0; r < 5; ++r) {
+            CK(hipEventRecord(e0, 0));
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, 0, (const cal_f4*)a, (cal_f4*)b, bytes / 16);
+            CK(hipEventRecord(e1, 0));
+            CK(hipDeviceSynchronize());
+            float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+            best = ms < best ? ms : best;
+        }
+        printf("\"%s\": {\"ms\": %.4f, \"read_plus_write_TBps\": %.3f}%s", name, best, 2.0 * bytes / best / 1e9, last ? "" : ", ");
+    };
+    run("plain stores, grid 2048", cal_copy16<false>, 2048, false);
+    run("plain stores, grid 8192", cal_copy16<false>, 8192, false);
+    run("plain stores, one 16 B per thread", cal_copy16<false>, (unsigned)(bytes / 16 / 256), false);
+    run("non-temporal stores, grid 2048", cal_copy16<true>, 2048, false);
+    run("non-temporal stores, grid 8192", cal_copy16<true>, 8192, false);
+    run("non-temporal stores, one 16 B per thread", cal_copy16<true>, (unsigned)(bytes / 16 / 256), true);
+    printf("}}\n");
+    CK(hipFree(a)); CK(hipFree(b));
+}
+
 int main(int argc, char** argv) {
+    if (argc > 1 && !strcmp(argv[1], "copy")) { run_copy(); return 0; }
     if (argc > 1 && !strcmp(argv[1], "hbm")) run_hbm();
     else if (argc > 1 && !strcmp(argv[1], "valu")) run_valu();
     else if (argc > 1 && !strcmp(argv[1], "atomics")) run_atomic_shapes();

@@ -873,7 +873,7 @@ int TerrainRenderer::frame_status(uint32_t out[4]) {
 }
 
 int TerrainRenderer::set_normals_lds_rows(int rows) {
-    if (rows != 4 && rows != 8 && rows != 16 && rows != 32 && rows != 64) return fail(TOPO_ERR_INVALID, "lds rows must be 4, 8, 16, 32 or 64");
+    if (rows != 0 && rows != 4 && rows != 8 && rows != 16 && rows != 32 && rows != 64) return fail(TOPO_ERR_INVALID, "lds rows must be 4, 8, 16, 32 or 64 (0: the form without an LDS tile)");
     lds_rows_ = rows;
     return TOPO_OK;
 }

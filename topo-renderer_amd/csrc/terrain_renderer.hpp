@@ -118,7 +118,8 @@ class TerrainRenderer {
     std::map<GeoKey, Tile> tiles_;
     uint64_t next_seq_ = 1;
     bool table_dirty_ = true;
-    int lds_rows_ = 32;       // LDS tile height of k_normals_interior: 32 rows is the sweep optimum (profiles/r02_normals_lds_sweep.json)
+    int lds_rows_ = 0;        // interior normals: 0 = without an LDS tile (k_normals_rolling: the sweep's optimum, profiles/r03_normals_lds_sweep.json;
+                              // needs a tile width that is a multiple of four, else the LDS form with 32 rows); 4..64 = LDS tile height of k_normals_interior
     uint32_t big_cap_cfg_ = 0, rare_cap_cfg_ = 0;
     uint64_t rare_cap_auto_ = 0;           // rare-queue capacity topo_render grew to after an overflow (0 = default)
     uint32_t timing_slots_ = 0x3Fu;        // topo_set_timing_slots: which per-kernel durations to measure

@@ -118,19 +118,36 @@ __global__ __launch_bounds__(256) void k_block_tables(const TileDev* __restrict_
         float mn[4], mx[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) { mn[k] = INFINITY; mx[k] = -INFINITY; }
-        for (uint32_t r = 0; r < nrows; ++r) {
-            const auto row = heights + (size_t)(y0 + r) * w + c0;
-            float v[4];
+        if ((w & 3u) == 0u) {
+            // rows are 16-byte aligned and c0 = 240 (run) is a multiple of four: lane i reads columns 4 i .. 4 i + 3 in ONE load
+            typedef float f32x4_t __attribute__((ext_vector_type(4)));
+            const uint32_t cl = 4 * lane < ncols ? 4 * lane : (ncols - 1) & ~3u;      // (surplus lanes re-read the last vector: it exists, w % 4 == 0)
+            for (uint32_t r = 0; r < nrows; ++r) {
+                const f32x4_t v = *(const __attribute__((address_space(1))) f32x4_t*)(heights + (size_t)(y0 + r) * w + c0 + cl);
+                mn[0] = fminf(mn[0], v.x); mx[0] = fmaxf(mx[0], v.x);
+                mn[1] = fminf(mn[1], v.y); mx[1] = fmaxf(mx[1], v.y);
+                mn[2] = fminf(mn[2], v.z); mx[2] = fmaxf(mx[2], v.z);
+                mn[3] = fminf(mn[3], v.w); mx[3] = fmaxf(mx[3], v.w);
+            }
+            if (lane < 64) {      // (columns beyond ncols hold copies of real columns of this run or, in its last vector, of the tile's last columns: never read below)
 #pragma unroll
-            for (uint32_t k = 0; k < 4; ++k) {
-                const uint32_t c = lane + 64 * k;
-                v[k] = row[c < ncols ? c : ncols - 1];      // (unconditional loads; the surplus lanes re-read the last column)
+                for (uint32_t k = 0; k < 4; ++k) { s_mn[wave][(4 * lane + k) & 255u] = mn[k]; s_mx[wave][(4 * lane + k) & 255u] = mx[k]; }
+            }
+        } else {
+            for (uint32_t r = 0; r < nrows; ++r) {
+                const auto row = heights + (size_t)(y0 + r) * w + c0;
+                float v[4];
+#pragma unroll
+                for (uint32_t k = 0; k < 4; ++k) {
+                    const uint32_t c = lane + 64 * k;
+                    v[k] = row[c < ncols ? c : ncols - 1];      // (unconditional loads; the surplus lanes re-read the last column)
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { mn[k] = fminf(mn[k], v[k]); mx[k] = fmaxf(mx[k], v[k]); }
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { mn[k] = fminf(mn[k], v[k]); mx[k] = fmaxf(mx[k], v[k]); }
+            for (uint32_t k = 0; k < 4; ++k) { s_mn[wave][lane + 64 * k] = mn[k]; s_mx[wave][lane + 64 * k] = mx[k]; }
         }
-#pragma unroll
-        for (uint32_t k = 0; k < 4; ++k) { s_mn[wave][lane + 64 * k] = mn[k]; s_mx[wave][lane + 64 * k] = mx[k]; }
         // ---- the f64 sin/cos pairs: lanes 0..2 latitudes (y0, y1, centre), lanes 3 + 3 b .. 5 + 3 b longitudes (x0, x1, centre) of block b
         const double D2R = 0.017453292519943295;
         const double yy0 = (double)(by * kBCY);
@@ -231,6 +248,18 @@ __global__ __launch_bounds__(256) void k_block_tables(const TileDev* __restrict_
     }
 }
 
+// Workgroups are dealt round-robin over the chip's eight XCDs (each with an L2 of its own), so the workgroups that share an L2
+// are L, L + 8, L + 16, ... of the launch order -- and neighbouring pieces of a tile, which re-read each other's halo rows and
+// columns, never meet in one.  (Measured on the c4 load phase: FETCH_SIZE 1.54x the DEM for the LDS form, 1.25x for the
+// LDS-less one -- exactly their halo ratios: every halo line came over the fabric again.)  This hands each XCD a CONTIGUOUS
+// eighth of a launch's pieces instead: piece = (L % 8) * ceil(n / 8) + L / 8.  A speed matter only (nothing depends on
+// which XCD runs what); returns false for the slack pieces at the end.
+__device__ __forceinline__ bool xcd_contiguous_piece(uint32_t n_pieces, uint32_t& piece) {
+    const uint32_t L = blockIdx.x, per_xcd = (n_pieces + 7u) / 8u;
+    piece = (L & 7u) * per_xcd + (L >> 3);
+    return (L >> 3) < per_xcd && piece < n_pieces;
+}
+
 // Interior normals (compute_normals_shader.wgsl:22-51) of a batch of tiles (blockIdx.z).  128 x ROWS output texels per
 // 256-thread workgroup, TWO horizontally adjacent texels per lane: the kernel issues as many instructions as it moves
 // bytes (one texel per lane: ~90 instructions per 64 texels, 0.21 ms of issue slots beside 0.20 ms of HBM time at c4), and
@@ -247,14 +276,19 @@ __global__ __launch_bounds__(256) void k_block_tables(const TileDev* __restrict_
 typedef float f32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));         // a pair of floats at any 4-byte boundary
 typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
 template <int ROWS>
-__global__ __launch_bounds__(256) void k_normals_interior(const TileDev* __restrict__ tiles, uint32_t first, int W, int H) {
+__global__ __launch_bounds__(256) void k_normals_interior(const TileDev* __restrict__ tiles, uint32_t first, uint32_t n_tiles, int W, int H) {
     // column c of the tile (c = -1 .. 128) lives at index c + 2: a lane's pair (2 tx, 2 tx + 1) at the even index 2 tx + 2
     __shared__ __attribute__((aligned(16))) float tile[ROWS + 2][132];
     __shared__ float s_ys[ROWS];
-    const TileDev& t = tiles[first + blockIdx.z];
+    // pieces = (tile, row band, column block), column block fastest; handed out XCD by XCD (xcd_contiguous_piece)
+    const uint32_t gx = ((uint32_t)W + 127u) / 128u, gy = ((uint32_t)H + ROWS - 1u) / ROWS;
+    uint32_t piece;
+    if (!xcd_contiguous_piece(gx * gy * n_tiles, piece)) return;      // (workgroup-uniform: before any barrier)
+    const uint32_t bz = piece / (gx * gy), by_ = (piece - bz * gx * gy) / gx, bx_ = piece - bz * gx * gy - by_ * gx;
+    const TileDev& t = tiles[first + bz];
     const auto heights = TOPO_GLOBAL_F32(t.heights);          // global, not flat, memory operations
     const auto normals = TOPO_GLOBAL_U32_RW(t.normals);
-    const int x0 = blockIdx.x * 128, y0 = blockIdx.y * ROWS;
+    const int x0 = (int)bx_ * 128, y0 = (int)by_ * ROWS;
     const int tx = threadIdx.x & 63, wy = threadIdx.x >> 6;
     const int gx0 = x0 + 2 * tx;                              // the lane's first column (the second: gx0 + 1)
     {
@@ -319,6 +353,97 @@ __global__ __launch_bounds__(256) void k_normals_interior(const TileDev* __restr
             __builtin_nontemporal_store(v, (__attribute__((address_space(1))) u32x2_a4*)(out));
         } else if (gx0 < W) {
             *out = t0;
+        }
+    }
+}
+
+// The same pass WITHOUT an LDS tile (topo_set_normals_lds_rows(0); needs a tile width that is a multiple of four): a wave owns
+// a strip of 256 columns -- FOUR adjacent texels per lane, one 16-byte load and one 16-byte store per lane and row -- and
+// walks kRollRows rows of it top to bottom with the rows above and below the current one kept in registers (each height is
+// loaded once per strip and chunk; the chunk's first and last rows twice), the next four rows always in flight.  The texel
+// left of a lane's first and right of its last come from the neighbouring lanes by DPP wave shifts; the two columns beside
+// the strip by one extra two-address load per row.  No barrier, no LDS traffic, 1 KiB per wave and memory instruction.
+// cos(latitude) of a row is the tile's trig_lat table entry (k_block_tables: the same function of the same input).
+__device__ __forceinline__ float unif2(float v, int src_lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane)); }
+__device__ __forceinline__ float unif_first(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float wave_from_left(float v, float first) {      // lane i: lane i - 1's v; lane 0: `first`
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(first), __float_as_int(v), 0x138 /* wave_shr:1 */, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float wave_from_right(float v, float last) {      // lane i: lane i + 1's v; lane 63: `last`
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(last), __float_as_int(v), 0x130 /* wave_shl:1 */, 0xF, 0xF, false));
+}
+template <int kRollRows, int kWaves>
+__global__ __launch_bounds__(64 * kWaves) void k_normals_rolling(const TileDev* __restrict__ tiles, uint32_t first, uint32_t n_tiles, int W, int H) {
+    const uint32_t gx = ((uint32_t)W + 255u) / 256u, gy = (((uint32_t)H + kRollRows - 1u) / kRollRows + kWaves - 1u) / kWaves;
+    uint32_t piece;
+    if (!xcd_contiguous_piece(gx * gy * n_tiles, piece)) return;
+    const uint32_t bz = piece / (gx * gy), by_ = (piece - bz * gx * gy) / gx, bx_ = piece - bz * gx * gy - by_ * gx;
+    const TileDev& t = tiles[first + bz];
+    const auto heights = TOPO_GLOBAL_F32(t.heights);
+    const auto normals = TOPO_GLOBAL_U32_RW(t.normals);
+    const auto trig_lat = TOPO_GLOBAL_F32(t.trig_lat);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int x0 = (int)bx_ * 256, c0 = x0 + 4 * lane;
+    const int y0 = ((int)by_ * kWaves + wave) * kRollRows;
+    if (y0 >= H) return;
+    const int y1 = y0 + kRollRows < H ? y0 + kRollRows : H;      // rows [y0, y1)
+    const bool col_active = c0 < W;                               // (W % 4 == 0: a lane's four columns are all inside or all outside)
+    const int cc = col_active ? c0 : W - 4;
+    // the two columns beside the strip, one load for both: lanes 0..31 the left one, lanes 32..63 the right one (clamped)
+    const int ce = lane < 32 ? (x0 > 0 ? x0 - 1 : 0) : (x0 + 256 < W ? x0 + 256 : W - 1);
+    auto row_ptr = [&](int y) { return heights + (size_t)(y < 0 ? 0 : (y > H - 1 ? H - 1 : y)) * W; };
+    auto load4 = [&](int y) { return *(const __attribute__((address_space(1))) f32x4_t*)(row_ptr(y) + cc); };
+    auto load_edge = [&](int y) { return row_ptr(y)[ce]; };
+    const float xs = deg2rad(t.scale_x) * kR0, ys0 = deg2rad(t.scale_y) * kR0;
+    // rows y - 1 and y of the first output row, then four new rows per round
+    f32x4_t above = load4(y0 - 1), mid = load4(y0);
+    float mid_edge = load_edge(y0);
+    f32x4_t nx[4];
+    float ne[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { nx[k] = load4(y0 + 1 + k); ne[k] = load_edge(y0 + 1 + k); }
+    auto out = normals + ((size_t)y0 * W + cc);
+    for (int y = y0; y < y1; y += 4) {
+        f32x4_t cur[4];
+        float ce4[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { cur[k] = nx[k]; ce4[k] = ne[k]; }
+        if (y + 4 < y1) {      // (wave-uniform) the next round's rows: in flight under this round's arithmetic
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { nx[k] = load4(y + 5 + k); ne[k] = load_edge(y + 5 + k); }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int gy = y + k;
+            if (gy >= y1) break;      // (wave-uniform)
+            const f32x4_t below = cur[k];
+            const float ys = ys0 * unif_first(trig_lat[2 * gy + 1]);
+            const float left_edge = unif2(mid_edge, 0), right_edge = unif2(mid_edge, 63);
+            const float hl = wave_from_left(mid.w, left_edge), hr = wave_from_right(mid.x, right_edge);
+            const bool row_in = gy >= 1 && gy < H - 1;
+            const float hL[4] = {hl, mid.x, mid.y, mid.z}, hR[4] = {mid.y, mid.z, mid.w, hr};
+            const float hT[4] = {above.x, above.y, above.z, above.w}, hB[4] = {below.x, below.y, below.z, below.w};
+            uint32_t tex[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int gx = c0 + q;
+                const bool in = row_in && gx >= 1 && gx < W - 1;
+                uint32_t v = 0;
+                const bool settled = normal_texel_fast(xs, ys, hT[q], hL[q], hR[q], hB[q], v) || !in;
+                if (!settled) v = normal_texel(xs, ys, hT[q], hL[q], hR[q], hB[q]);      // the guard band and non-finite heights: the full chain
+                tex[q] = in ? v : 0u;
+            }
+            if (col_active) {
+                u32x4_t o;
+                o.x = tex[0]; o.y = tex[1]; o.z = tex[2]; o.w = tex[3];
+                __builtin_nontemporal_store(o, (__attribute__((address_space(1))) u32x4_t*)(out));
+            }
+            out += W;
+            above = mid;
+            mid = below;
+            mid_edge = ce4[k];
         }
     }
 }
@@ -1741,9 +1866,27 @@ void launch_normals_interior(const TileDev* tiles, uint32_t first, uint32_t coun
                              hipStream_t s) {
     if (count == 0) return;
     const dim3 block(256);
-#define TOPO_K1(R)                                                                                                     \
-    hipLaunchKernelGGL(k_normals_interior<R>, dim3((w + 127) / 128, (h + (R)-1) / (R), count), block, 0, s, tiles, first, \
-                       (int)w, (int)h)
+    if (lds_rows == 0 && w % 4 == 0) {      // the register-rolling form: no LDS tile
+        // rows per wave x waves per workgroup.  Measured on the c4 load phase (tools/exp_roll.py, ms for K1-K3 of 100 tiles, +-2 %):
+        // 4x1 0.211, 4x4 0.217, 8x1 0.222, 8x4 0.223, 16x4 0.238, 48x4 0.242; one row per wave 0.232; the LDS form with 32 rows
+        // 0.225-0.233.  Short-lived single-wave workgroups stream best (a plain 16-byte copy of the same bytes: 6.3 TB/s as one
+        // load and one store per thread, 5.0-5.3 as a grid-stride loop: tools/calib.hip copy).  TOPO_ROLL_SHAPE = rows * 10 + waves.
+        static const int shape = getenv("TOPO_ROLL_SHAPE") ? atoi(getenv("TOPO_ROLL_SHAPE")) : 41;
+#define TOPO_ROLL(R, WV) hipLaunchKernelGGL((k_normals_rolling<R, WV>), dim3(((((w + 255) / 256) * (((h + (R)-1) / (R) + (WV)-1) / (WV)) * count + 7) / 8) * 8), dim3(64 * (WV)), 0, s, tiles, first, count, (int)w, (int)h)
+        switch (shape) {
+            case 44: TOPO_ROLL(4, 4); break;
+            case 81: TOPO_ROLL(8, 1); break;
+            case 84: TOPO_ROLL(8, 4); break;
+            case 164: TOPO_ROLL(16, 4); break;
+            case 484: TOPO_ROLL(48, 4); break;
+            default: TOPO_ROLL(4, 1); break;
+        }
+#undef TOPO_ROLL
+        return;
+    }
+#define TOPO_K1(R)                                                                                                                    \
+    hipLaunchKernelGGL(k_normals_interior<R>, dim3(((((w + 127) / 128) * ((h + (R)-1) / (R)) * count + 7) / 8) * 8), block, 0, s, tiles, first, \
+                       count, (int)w, (int)h)
     switch (lds_rows) {
         case 4: TOPO_K1(4); break;
         case 8: TOPO_K1(8); break;

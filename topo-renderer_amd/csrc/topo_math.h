@@ -300,16 +300,24 @@ TOPO_HD bool normal_texel_fast(float x, float y, float hT, float hL, float hR, f
     const float r = 1.0f / sqrtf(ss);          // (test builds: also within 1 ulp of the reciprocal square root)
 #endif
     const float tx = fmaf(vx * r, 127.5f, 128.0f), ty = fmaf(vy * r, 127.5f, 128.0f), tz = fmaf(vz * r, 127.5f, 128.0f);
-    const float fx = floorf(tx), fy = floorf(ty), fz = floorf(tz);
-    const float gx = tx - fx, gy = ty - fy, gz = tz - fz;      // exact: t in [0, 256)
     // |g - 1/2| <= 1/2 - guard  <=>  guard <= g <= 1 - guard up to the rounding of g - 1/2 (6e-8: the guard band has 1.2e-4 to
-    // spare).  ss >= 1e-30 keeps the squares' underflow out of the error bound (a term that underflows is < 1e-8 of such an
-    // ss); with it |v_i r| <= 1 + 1e-6, so t lies in [0.49, 255.51] and needs no range test: an overflowed ss gives r = 0,
-    // t = 128, g = 0; a NaN anywhere fails every comparison.  (Seven instructions instead of twenty-three: the kernel is as
-    // much bound by instruction issue as by HBM.)
+    // spare), g = the fractional part of t.  ss >= 1e-30 keeps the squares' underflow out of the error bound (a term that
+    // underflows is < 1e-8 of such an ss); with it |v_i r| <= 1 + 1e-6, so t lies in [0.49, 255.51] and needs no range test:
+    // there the fractional part is exact, the conversion to integer truncates = floors, and an overflowed ss gives r = 0,
+    // t = 128 (or NaN where v_i is infinite), g_y = g_z = 0: refused; a NaN height makes ss NaN, which fails the first test.
+    // (The kernel is as much bound by instruction issue as by HBM: on the device the fractional part is one instruction
+    // (v_fract_f32: exact for t >= 0), the three band tests are one three-way maximum and one comparison, the codes come
+    // straight from t.)
     constexpr float kLim = 0.5f - kNormalGuard;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float gx = __builtin_amdgcn_fractf(tx), gy = __builtin_amdgcn_fractf(ty), gz = __builtin_amdgcn_fractf(tz);
+    const float worst = fmaxf(fmaxf(fabsf(gx - 0.5f), fabsf(gy - 0.5f)), fabsf(gz - 0.5f));      // (a NaN operand is ignored: see above why none can decide)
+    const bool ok = ss >= 1.0e-30f && worst <= kLim;
+#else
+    const float gx = tx - floorf(tx), gy = ty - floorf(ty), gz = tz - floorf(tz);      // exact: t in [0, 256)
     const bool ok = ss >= 1.0e-30f && fabsf(gx - 0.5f) <= kLim && fabsf(gy - 0.5f) <= kLim && fabsf(gz - 0.5f) <= kLim;
-    texel = (uint32_t)fx | ((uint32_t)fy << 8) | ((uint32_t)fz << 16);      // alpha: to_unorm8(0) = 0
+#endif
+    texel = (uint32_t)tx | ((uint32_t)ty << 8) | ((uint32_t)tz << 16);      // (truncation = floor for t >= 0; alpha: to_unorm8(0) = 0; not used unless ok)
     return ok;
 }
 
