@@ -1108,7 +1108,7 @@ int TerrainRenderer::probe_sincos(const float* x, float* s, float* c, size_t n) 
 }
 
 int TerrainRenderer::probe_div(int32_t kind, const float* x, const float* y, float* out, size_t n) {
-    if (kind < 0 || kind > 3 || !x || !y || !out) return fail(TOPO_ERR_INVALID, "probe_div: bad argument");
+    if (kind < 0 || kind > 5 || !x || !y || !out) return fail(TOPO_ERR_INVALID, "probe_div: bad argument");
     if (int rc = bind_device()) return rc;
     float *dx = nullptr, *dy = nullptr, *dq = nullptr;
     TOPO_HIP_TRY(hipMalloc((void**)&dx, n * 4));

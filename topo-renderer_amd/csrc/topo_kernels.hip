@@ -1846,6 +1846,8 @@ __global__ void k_probe_div(int kind, const float* x, const float* y, float* out
     out[i] = kind == 0   ? div_f(x[i], y[i])
              : kind == 1 ? div_const(x[i], 255.0f, 1.0f / 255.0f)
              : kind == 2 ? div_const(x[i], 0.15f - 0.05f, 1.0f / (0.15f - 0.05f))
+             : kind == 4 ? __builtin_amdgcn_fractf(x[i])      // v_fract_f32, the instruction itself
+             : kind == 5 ? fract_f(x[i])                       // the spec's fract as the kernels evaluate it
                          : sqrt_f(x[i]);
 }
 
