@@ -463,14 +463,16 @@ def collect_pmc(args, kernel):
             if args.occlusion_split is not None:
                 cmd += ["--occlusion-split", str(args.occlusion_split)]
             try:
-                subprocess.run(cmd, cwd=tmp, env=dict(os.environ, TMPDIR=tmp), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
+                subprocess.run(cmd, cwd=tmp, env=dict(os.environ, TMPDIR=tmp), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=240, check=True)
             except (subprocess.SubprocessError, OSError) as e:
-                out["error"] = f"rocprofv3 --pmc {grp.split()[0]}... failed: {type(e).__name__}"
+                tail = (getattr(e, "stderr", None) or b"").decode("utf-8", "replace").strip().split("\n")[-3:]
+                out["error"] = f"rocprofv3 --pmc {grp.split()[0]}... failed: {type(e).__name__} {getattr(e, 'returncode', '')} {' | '.join(t[-160:] for t in tail)}"
                 continue
             vals = {}
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
-                    if kernel + "(" in row["Kernel_Name"] or row["Kernel_Name"].rstrip().endswith(kernel):
+                    name = row["Kernel_Name"]      # "void topo::(anonymous namespace)::k_resolve<true, false>(topo::FrameParams, ...)"
+                    if kernel + "(" in name or kernel + "<" in name or name.rstrip().endswith(kernel):
                         vals.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
             for c, v in vals.items():
                 v.sort()
