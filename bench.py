@@ -319,13 +319,18 @@ def main():
         "gpu_ms_per_step": {"mean": round(timed_ms["total"], 4), "median": round(timed_median["total"], 4), dom + "_median": round(timed_median[dom], 4),
                             "frames": timed_frames, "what": "first to last HIP event of a frame of the timed region (topo_get_timing_history, read after the region)"},
         "load_ms": round(load_ms, 4),
-        "load_what": "every load-time kernel of the resident tiles: k_block_tables (block min/max, cull bounds, sin/cos tables: this design's own) + normals K1-K3",
+        "load_what": "every load-time kernel of the resident tiles, the DEM read ONCE: k_trig_tables (sin/cos tables) -> k_normals_rolling<4,4,true> (interior normals K1 "
+                     "+ the raster blocks' min/max heights in the same pass) -> k_block_bounds (f64 cull bounds from them) -> k_normals_border (K2, K3); "
+                     "with TOPO_LOAD_FUSED=0: k_block_tables (a second DEM read) + the normals kernels",
+        "load_fused": os.environ.get("TOPO_LOAD_FUSED", "1") != "0",
         "load_tables_ms": round(load_tables_ms, 4),
         "load_normals_ms": round(load_normals_ms, 4),
         "load_normals_GBps": round(8.0 * n_tiles * TILE * TILE / (load_normals_ms / 1e3) / 1e9, 1) if load_normals_ms > 0 else None,
         "load_normals_frac_hbm_peak": round(8.0 * n_tiles * TILE * TILE / (load_normals_ms / 1e3) / 1e9 / HBM_PEAK_GBPS, 4) if load_normals_ms > 0 else None,
         "load_GBps": round(8.0 * n_tiles * TILE * TILE / (load_ms / 1e3) / 1e9, 1) if load_ms > 0 else None,
-        "load_GBps_what": "SURVEY 8(d) load-phase bytes (4 B read + 4 B written per texel) over the WHOLE load phase incl. the tables kernel (which reads the DEM a second time)",
+        "load_tables_what": "the kernels in front of the normals pass (fused path: k_trig_tables alone; separate path: k_block_tables); load_normals_ms = the rest "
+                            "(fused path: normals + block min/max + f64 bounds + seams)",
+        "load_GBps_what": "SURVEY 8(d) load-phase bytes (4 B read + 4 B written per texel) over the WHOLE load phase, this design's own tables included",
         "add_terrain_ms_per_tile": round(1e3 * upload_s / n_tiles, 3),
         "add_terrain_what": "topo_add_terrain per tile from pageable host memory: one pooled allocation, the 5.76 MB upload, tables + normals + seam passes, one stream sync",
         "hbm_read_roofline_frac_frame": round((4.0 * n_tiles * TILE * TILE / (ms_per_step / 1e3) / 1e9) / HBM_PEAK_GBPS, 5),

@@ -23,6 +23,12 @@ int topo_debug_set_queue_caps(topo_ctx* ctx, uint32_t big_cap, uint32_t rare_cap
 /* Test accessor: the tile's Rgba8Unorm normal texture, w*h*4 bytes, host pointer. */
 int topo_read_normals(topo_ctx* ctx, int32_t lat_deg, int32_t lon_deg, uint8_t* out);
 
+/* The load-time tables of a tile, read back (unit tests: the two load paths must leave the same tables).  minmax_out: 2 floats per
+ * raster block (60 x 15 cells); trig_out: 2 (w + h) floats, the (sin, cos) pairs of the w vertex longitudes, then of the h vertex
+ * latitudes; bounds_out: 17 doubles per raster block (4 sphere | 12 corner directions | 1 sagitta, each part contiguous over the
+ * blocks).  Any pointer may be null.  n_blocks_out: the number of raster blocks. */
+int topo_read_tile_tables(topo_ctx* ctx, int32_t lat_deg, int32_t lon_deg, float* minmax_out, float* trig_out, double* bounds_out, uint32_t* n_blocks_out);
+
 /* Synthetic COP90-shaped tile for tests and benches (integer-hash fBm): w*h floats. */
 void topo_synth_tile(int32_t lat_deg, int32_t lon_deg, uint32_t w, uint32_t h, uint32_t seed, float* out);
 
@@ -30,7 +36,9 @@ void topo_synth_tile(int32_t lat_deg, int32_t lon_deg, uint32_t w, uint32_t h, u
 int topo_probe_sincos(topo_ctx* ctx, const float* x, float* s, float* c, size_t n);
 
 /* GPU unit-test probe: the device forms of the spec's IEEE divisions over n host floats.  kind 0: x / y (general
- * form, operands inside 2^-96 .. 2^96); kind 1: x / 255; kind 2: x / (0.15f - 0.05f); kind 3: sqrt(x) (y ignored for 1..3). */
+ * form, operands inside 2^-96 .. 2^96); kind 1: x / 255; kind 2: x / (0.15f - 0.05f); kind 3: sqrt(x) (y ignored for 1..5);
+ * kind 4: the v_fract_f32 instruction; kind 5: the spec's x - floor(x); kinds 6..8: channel kind - 6 of fs_main's mode-0 colour
+ * (render_shader.wgsl:75-87,106) for the dither argument p = (x, y) and a shading of 0.25. */
 int topo_probe_div(topo_ctx* ctx, int32_t kind, const float* x, const float* y, float* out, size_t n);
 
 #ifdef __cplusplus

@@ -60,6 +60,60 @@ def test_division_probe(topo):
         assert np.array_equal(got[nz].view(np.uint32), (xs / c)[nz].view(np.uint32))
 
 
+def _hash12n_f32(sx, sy):
+    """render_shader.wgsl:75-79 in numpy binary32, one rounding per operation (fract(e) = e - floor(e))."""
+    f = np.float32
+    fract = lambda v: v - np.floor(v)
+    px, py = fract(sx * f(5.3987)), fract(sy * f(5.4421))
+    d = py * (px + f(21.5351)) + px * (py + f(14.3137))
+    px, py = px + d, py + d
+    return fract(px * py * f(95.4307))
+
+
+def test_fract_probe(topo):
+    """The dither's fractions on the device: v_fract_f32 is x - floor(x) except for the negatives above -2^-24, and the
+    wave-level window test of shade_fragment (topo_math.h) keeps those on the two-instruction form."""
+    r = topo.TerrainRenderer(8, 8)
+    rng = np.random.default_rng(11)
+    f = np.float32
+    n = 1 << 20
+    x = np.concatenate([rng.uniform(-4.0e6, 4.0e6, n), rng.uniform(-2.0, 2.0, n), -np.exp2(rng.uniform(-60.0, -20.0, n)),
+                        np.exp2(rng.uniform(-60.0, 30.0, n)), [0.0, -0.0, -1.0, 1.0, -2.0 ** -24, -2.0 ** -25, np.inf, -np.inf]]).astype(f)
+    with np.errstate(all="ignore"):
+        ref = x - np.floor(x)
+    same = lambda a, b: (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
+    assert same(r.probe_div(5, x, x), ref).all()
+    instr = r.probe_div(4, x, x)
+    differ = ~same(instr, ref)
+    assert differ.any() and ((x[differ] < 0) & (x[differ] > -f(2.0) ** -24)).all()
+    assert (instr[differ] == np.nextafter(f(1.0), f(0.0))).all() and (ref[differ] == 1.0).all()
+    # the dither itself, channel by channel, against the numpy restatement: arguments all over the range the path produces and
+    # clustered on the twelve first-level zeros p = -c (a few ulps either side), alone and mixed into waves of ordinary pixels
+    offs = [f(0.0), f(0.07), f(0.11), f(0.13), f(0.13) + f(0.07), f(0.13) + f(0.11)]
+    m = 1 << 18
+    px, py = rng.uniform(-5.0e5, 5.0e5, m).astype(f), rng.uniform(-5.0e5, 5.0e5, m).astype(f)
+    near = np.array([-c + f(k) * np.spacing(c) for c in offs[1:] for k in range(-8, 9)] + [-(2.0 ** -k) for k in range(20, 60)], dtype=f)
+    chains = [near, near + f(0.07), near + f(0.11), near + f(0.13), (near + f(0.13)) + f(0.07), (near + f(0.13)) + f(0.11)]
+    risky = [((v * f(5.3987) < 0) & (v * f(5.3987) > -f(2.0) ** -24)).sum() for v in chains]
+    assert all(risky[k] > 0 for k in (0, 1, 2, 4)), risky      # (the sample reaches the instruction's exceptional range through every chain that can:
+    #                                                               p + 0.13 near zero is a multiple of 1.5e-8, times 5.4 beyond 2^-24)
+    near = np.concatenate([near, -near, near * f(0.5)])
+    sel = rng.integers(0, m, near.size * 2)
+    px[sel[:near.size]] = near                     # one risky pixel inside otherwise ordinary waves
+    py[sel[near.size:]] = near
+    px = np.concatenate([px, np.tile(near, 8)])    # and whole waves of them
+    py = np.concatenate([py, rng.uniform(-3.0, 3.0, near.size * 8).astype(f)])
+    qx, qy = px + f(0.13), py + f(0.13)
+    with np.errstate(all="ignore"):
+        for k, off in enumerate((f(0.0), f(0.07), f(0.11))):
+            h1 = _hash12n_f32(px + off, py + off) if k else _hash12n_f32(px, py)
+            h2 = _hash12n_f32(qx + off, qy + off) if k else _hash12n_f32(qx, qy)
+            want = f(0.01) + f(0.7) * (f(0.25) / f(0.7)) + f(1.0) * (h1 + h2 - f(1.0)) / f(255.0)
+            got = r.probe_div(6 + k, px, py)
+            bad = ~same(got, want.astype(f))
+            assert not bad.any(), (k, int(bad.sum()), px[bad][:4], py[bad][:4], got[bad][:4], want[bad][:4])
+
+
 @pytest.mark.parametrize("tile,n_lat,n_lon", [(64, 1, 1), (48, 2, 2), (33, 3, 3), (150, 1, 2)])
 def test_normals_byte_exact(topo, orc, tile, n_lat, n_lon):
     sc = Scene(tile, n_lat, n_lon)
@@ -415,6 +469,57 @@ def test_non_square_and_tiny_tiles(topo, orc, tw, th):
         g.update(W, H, u, topo.post_uniforms(W, H))
         o.update(W, H, u, topo.post_uniforms(W, H))
         assert_same_frame(g.render(), o.render(), f"{tw}x{th} tiles yaw {yaw}")
+
+
+@pytest.mark.parametrize("tw,th", [(240, 47), (480, 31), (240, 46), (240, 16), (720, 15)])
+def test_one_pass_load_path_equals_the_separate_kernels(topo, orc, tw, th):
+    """Tiles 240 k columns wide take the load path that reads the DEM once (k_trig_tables -> k_normals_rolling<4, 4, true>:
+    normals + block minima / maxima -> k_block_bounds).  Its normals are the oracle's, and every table it leaves -- block
+    min/max, sin/cos tables, f64 cull bounds -- is bit for bit what k_block_tables + the LDS-tile normals kernel leave."""
+    import math
+    W, H = 96, 64
+    locs = topo.synth.mosaic_locations(45, 15, 2, 2)
+    hts = {}
+    for (la, lo) in locs:
+        h = topo.synth_tile(la, lo, max(tw, th), max(tw, th))[:th, :tw].copy()
+        h[th // 3, tw // 5] = -12.5                     # a negative height, zeros of both signs and a spike on a block edge
+        h[0, 0], h[th - 1, tw - 1] = 0.0, -0.0
+        h[min(15, th - 1), 60] = 8000.0
+        hts[(la, lo)] = h
+    tr = lambda la, lo: (np.float32([0, 0]), np.float32([lo, la + 1]), np.float32([1.0 / tw, 1.0 / th]))
+    one, sep, o = topo.TerrainRenderer(W, H), topo.TerrainRenderer(W, H), orc.OracleRenderer(W, H)
+    sep.set_normals_lds_rows(8)                         # the LDS-tile kernel + k_block_tables
+    for (la, lo) in locs:
+        for r in (one, sep, o):
+            r.add_terrain(la, lo, hts[(la, lo)], *tr(la, lo))
+    for loc in locs:
+        n1 = one.read_normals(*loc)
+        assert np.array_equal(n1, o.read_normals(loc[0], loc[1], tw, th)), loc
+        assert np.array_equal(n1, sep.read_normals(*loc)), loc
+        a, b = one.read_tile_tables(*loc), sep.read_tile_tables(*loc)
+        assert a["minmax"].shape[0] == ((tw - 1 + 59) // 60) * ((th - 1 + 14) // 15)
+        for k in ("minmax", "trig", "bounds"):
+            assert np.array_equal(a[k].view(np.uint8), b[k].view(np.uint8)), (loc, k, np.argwhere(a[k] != b[k])[:4])
+        # the minima / maxima against numpy on the blocks' vertex ranges
+        bxc = (tw - 1 + 59) // 60
+        for blk, (lo_, hi_) in enumerate(a["minmax"]):
+            by, bx = divmod(blk, bxc)
+            v = hts[loc][15 * by:min(15 * by + 16, th), 60 * bx:min(60 * bx + 61, tw)]
+            assert lo_ == v.min() and hi_ == v.max(), (loc, blk)
+    one.recompute_normals()                             # the batched form (all tiles in one launch of each kernel)
+    for loc in locs:
+        assert np.array_equal(one.read_normals(*loc), sep.read_normals(*loc)), loc
+        a, b = one.read_tile_tables(*loc), sep.read_tile_tables(*loc)
+        for k in ("minmax", "trig", "bounds"):
+            assert np.array_equal(a[k].view(np.uint8), b[k].view(np.uint8)), (loc, k)
+    eye = topo.geometry_transform(float(hts[(46, 16)].max()) + 900.0, 16.02, 46.03)
+    u = topo.camera_uniforms(eye, math.radians(20), math.radians(25), math.radians(90), W, H, 16.0, 46.0, 0)
+    for r in (one, sep, o):
+        r.update(W, H, u, topo.post_uniforms(W, H))
+    f1 = one.render()
+    assert_same_frame(f1, o.render(), f"{tw}x{th} tiles")
+    assert_same_frame(f1, sep.render(), f"{tw}x{th} tiles, separate kernels")
+    assert one.counters() == sep.counters()
 
 
 def test_hemispheres_replacement_and_draw_order(topo, orc):

@@ -28,6 +28,8 @@ for rows in (0, 4, 8, 16, 32, 64):
         tm = r.timings()
         ms.append(tm["load"] - tm["load_tables"])      # the normals K1-K3 (the load phase also holds the tables kernel, which has no LDS knob)
     best = min(ms[2:])
-    out.append({"lds_rows": rows, "lds_bytes": (rows + 2) * 132 * 4 + rows * 4, "load_ms": round(best, 4),
+    out.append({"lds_rows": rows, "lds_bytes": (rows + 2) * 132 * 4 + rows * 4 if rows else 128, "load_ms": round(best, 4),
+                "what": "k_normals_rolling<4,4,true> (no LDS tile; collects the block min/max too) + k_block_bounds + seams" if rows == 0 and os.environ.get("TOPO_LOAD_FUSED", "1") != "0"
+                else ("k_normals_rolling<4,1,false> + seams" if rows == 0 else "k_normals_interior<ROWS> + seams"),
                 "GBps": round(bytes_ / (best / 1e3) / 1e9, 1), "frac_of_8TBps": round(bytes_ / (best / 1e3) / 8e12, 4)})
 print(json.dumps({"workload": f"{deg}x{deg} deg mosaic, {deg*deg} tiles of 1200x1200", "algorithmic_bytes": bytes_, "sweep": out}))

@@ -99,6 +99,7 @@ def lib():
             "topo_set_occlusion_split": (C.c_int, [vp, f32]),
             "topo_set_timing_slots": (C.c_int, [vp, u32]),
             "topo_read_normals": (C.c_int, [vp, i32, i32, vp]),
+            "topo_read_tile_tables": (C.c_int, [vp, i32, i32, vp, vp, vp, vp]),
             "topo_probe_sincos": (C.c_int, [vp, vp, vp, vp, sz]),
             "topo_probe_div": (C.c_int, [vp, i32, vp, vp, vp, sz]),
             "topo_set_pipeline_depth": (C.c_int, [vp, i32]),
@@ -543,6 +544,15 @@ class TerrainRenderer:
 
     def set_occlusion_split(self, metres: float):
         self._check(lib().topo_set_occlusion_split(self._h, metres))
+
+    def read_tile_tables(self, lat_deg, lon_deg) -> dict:
+        """The load-time tables of a tile (topo_read_tile_tables, test hook): block min/max, sin/cos tables, f64 cull bounds."""
+        w, h = self.tile_size
+        n = C.c_uint32(0)
+        self._check(lib().topo_read_tile_tables(self._h, lat_deg, lon_deg, None, None, None, C.byref(n)))
+        minmax, trig, bounds = np.empty((n.value, 2), np.float32), np.empty((w + h, 2), np.float32), np.empty(n.value * 17, np.float64)
+        self._check(lib().topo_read_tile_tables(self._h, lat_deg, lon_deg, _p(minmax), _p(trig), _p(bounds), C.byref(n)))
+        return {"minmax": minmax, "trig": trig, "bounds": bounds}
 
     def read_normals(self, lat_deg, lon_deg) -> np.ndarray:
         w, h = self.tile_size

@@ -239,8 +239,7 @@ int TerrainRenderer::add_terrain(int32_t lat, int32_t lon, const float* heights,
         std::vector<EdgeJob> edges;
         std::vector<CornerJob> corners;
         collect_jobs(nt, rk, edges, corners);
-        launch_block_tables((const TileDev*)d_tiles_, rk.at(geo_key(lat, lon)), 1, tile_w_, tile_h_, stream_);
-        launch_normals_interior((const TileDev*)d_tiles_, rk.at(geo_key(lat, lon)), 1, tile_w_, tile_h_, lds_rows_, stream_);
+        launch_load_kernels(rk.at(geo_key(lat, lon)), 1, nullptr);
         if (int rc = run_seam_jobs(edges, corners)) return rc;
     }
     TOPO_HIP_TRY(hipStreamSynchronize(stream_));   // `heights` (and the job lists) are only borrowed for the call
@@ -250,6 +249,24 @@ int TerrainRenderer::add_terrain(int32_t lat, int32_t lon, const float* heights,
     }
     TOPO_HIP_TRY(hipGetLastError());
     return TOPO_OK;
+}
+
+// Every load-time kernel of tiles [first, first + count) of the device table except the seam passes.  Two forms: the DEM read
+// ONCE (k_trig_tables -> normals + block minima / maxima in one pass -> k_block_bounds; COP90 / COP30 widths) or the tables kernel
+// followed by the normals kernel (any size, any LDS tile size).  `mid`: recorded between the part that precedes the normals and
+// the rest (the load phase's timing bracket).
+void TerrainRenderer::launch_load_kernels(uint32_t first, uint32_t count, hipEvent_t mid) {
+    const TileDev* tiles = (const TileDev*)d_tiles_;
+    if (normals_tables_fused(tile_w_, tile_h_, lds_rows_)) {
+        launch_trig_tables(tiles, first, count, tile_w_, tile_h_, stream_);
+        if (mid) (void)hipEventRecord(mid, stream_);
+        launch_normals_tables(tiles, first, count, tile_w_, tile_h_, stream_);
+        launch_block_bounds(tiles, first, count, tile_w_, tile_h_, stream_);
+    } else {
+        launch_block_tables(tiles, first, count, tile_w_, tile_h_, stream_);
+        if (mid) (void)hipEventRecord(mid, stream_);
+        launch_normals_interior(tiles, first, count, tile_w_, tile_h_, lds_rows_, stream_);
+    }
 }
 
 // unload_terrain (terrain_renderer.rs:361-363): neighbours keep whatever seam normals they have.
@@ -280,9 +297,7 @@ int TerrainRenderer::recompute_normals() {
     // the whole load phase of the resident tiles, every load-time kernel inside the bracket: the tables of the frame phase
     // (ev 0 -> 2), then the normals K1-K3 (ev 2 -> 1)
     TOPO_HIP_TRY(hipEventRecord(load_ev_[0], stream_));
-    launch_block_tables((const TileDev*)d_tiles_, 0, (uint32_t)order.size(), tile_w_, tile_h_, stream_);
-    TOPO_HIP_TRY(hipEventRecord(load_ev_[2], stream_));
-    launch_normals_interior((const TileDev*)d_tiles_, 0, (uint32_t)order.size(), tile_w_, tile_h_, lds_rows_, stream_);
+    launch_load_kernels(0, (uint32_t)order.size(), load_ev_[2]);
     launch_seam_jobs(edges.size(), corners.size());
     TOPO_HIP_TRY(hipEventRecord(load_ev_[1], stream_));
     TOPO_HIP_TRY(hipStreamSynchronize(stream_));   // the job lists are locals
@@ -989,6 +1004,20 @@ int TerrainRenderer::read_normals(int32_t lat, int32_t lon, uint8_t* out) {
     return TOPO_OK;
 }
 
+int TerrainRenderer::read_tile_tables(int32_t lat, int32_t lon, float* minmax_out, float* trig_out, double* bounds_out, uint32_t* n_blocks_out) {
+    Tile* t = find(lat, lon);
+    if (!t) return fail(TOPO_ERR_NOT_FOUND, "no such tile");
+    if (int rc = bind_device()) return rc;
+    TOPO_HIP_TRY(hipStreamSynchronize(stream_));
+    const uint32_t bxc = (tile_w_ - 1 + kBCX - 1) / kBCX, byc = (tile_h_ - 1 + kBCY - 1) / kBCY;
+    const size_t nb = (size_t)bxc * byc;
+    if (n_blocks_out) *n_blocks_out = (uint32_t)nb;
+    if (minmax_out) TOPO_HIP_TRY(hipMemcpy(minmax_out, t->dev.block_minmax, nb * 2 * sizeof(float), hipMemcpyDeviceToHost));
+    if (trig_out) TOPO_HIP_TRY(hipMemcpy(trig_out, t->dev.trig_lon, 2 * ((size_t)tile_w_ + tile_h_) * sizeof(float), hipMemcpyDeviceToHost));
+    if (bounds_out) TOPO_HIP_TRY(hipMemcpy(bounds_out, t->dev.block_bounds, nb * 17 * sizeof(double), hipMemcpyDeviceToHost));
+    return TOPO_OK;
+}
+
 // ---- GeoTIFF (fetch_terrain's decode step, background_runner.rs:113-136) ---------------------------------------
 int geotiff_transform(const TiffInfo& ti, float rp[2], float mp[2], float ps[2]) {
     // CoordinateTransform::from_geo_tag_data (coordinate_transform.rs:23-57)
@@ -1108,7 +1137,7 @@ int TerrainRenderer::probe_sincos(const float* x, float* s, float* c, size_t n) 
 }
 
 int TerrainRenderer::probe_div(int32_t kind, const float* x, const float* y, float* out, size_t n) {
-    if (kind < 0 || kind > 5 || !x || !y || !out) return fail(TOPO_ERR_INVALID, "probe_div: bad argument");
+    if (kind < 0 || kind > 8 || !x || !y || !out) return fail(TOPO_ERR_INVALID, "probe_div: bad argument");
     if (int rc = bind_device()) return rc;
     float *dx = nullptr, *dy = nullptr, *dq = nullptr;
     TOPO_HIP_TRY(hipMalloc((void**)&dx, n * 4));

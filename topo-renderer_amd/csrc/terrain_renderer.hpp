@@ -82,6 +82,7 @@ class TerrainRenderer {
     int set_occlusion_split(float metres);
     int set_timing_slots(uint32_t mask);
     int read_normals(int32_t lat, int32_t lon, uint8_t* out);
+    int read_tile_tables(int32_t lat, int32_t lon, float* minmax_out, float* trig_out, double* bounds_out, uint32_t* n_blocks_out);      // test hook
     int geotiff_to_device(const uint8_t* bytes, size_t n, float** d_heights, uint32_t* w, uint32_t* h, float rp[2], float mp[2], float ps[2]);
     int geotiff_decode(const uint8_t* bytes, size_t n, float* heights_out, size_t capacity);
     int add_terrain_geotiff(int32_t lat, int32_t lon, const uint8_t* bytes, size_t n);
@@ -104,6 +105,7 @@ class TerrainRenderer {
     int run_seam_jobs(const std::vector<EdgeJob>& edges, const std::vector<CornerJob>& corners);
     int upload_seam_jobs(const std::vector<EdgeJob>& edges, const std::vector<CornerJob>& corners);
     void launch_seam_jobs(size_t n_edges, size_t n_corners);
+    void launch_load_kernels(uint32_t first, uint32_t count, hipEvent_t mid);      // tables + interior normals of a run of tiles
     std::map<GeoKey, uint32_t> ranks() const;
     Tile* find(int lat, int lon);
     int upload_tile_table();

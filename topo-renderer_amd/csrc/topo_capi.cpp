@@ -168,6 +168,11 @@ int topo_read_normals(topo_ctx* ctx, int32_t lat, int32_t lon, uint8_t* out) {
     TOPO_CALL(ctx->r->read_normals(lat, lon, out));
 }
 
+int topo_read_tile_tables(topo_ctx* ctx, int32_t lat, int32_t lon, float* minmax_out, float* trig_out, double* bounds_out, uint32_t* n_blocks_out) {
+    TOPO_GUARD(ctx);
+    TOPO_CALL(ctx->r->read_tile_tables(lat, lon, minmax_out, trig_out, bounds_out, n_blocks_out));
+}
+
 int topo_visible_peaks(topo_ctx* ctx, uint32_t n_peaks, const float* peaks_xyz, uint8_t* visible_out, uint32_t* xy_out) {
     TOPO_GUARD(ctx);
     TOPO_CALL(ctx->r->visible_peaks(n_peaks, peaks_xyz, visible_out, xy_out));

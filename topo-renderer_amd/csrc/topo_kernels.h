@@ -105,6 +105,12 @@ struct CornerJob {         // compute_normals_corner (compute_normals_corner_sha
 };
 
 void launch_block_tables(const TileDev* tiles, uint32_t first, uint32_t count, uint32_t w, uint32_t h, hipStream_t s);   // block min/max, cull bounds, sin/cos tables of `count` tiles
+// The load path that reads the DEM once, taken when normals_tables_fused(): launch_trig_tables -> launch_normals_tables (interior
+// normals AND the block minima / maxima) -> launch_block_bounds (the f64 cull bounds from them) [-> launch_normals_border].
+bool normals_tables_fused(uint32_t w, uint32_t h, int lds_rows);
+void launch_trig_tables(const TileDev* tiles, uint32_t first, uint32_t count, uint32_t w, uint32_t h, hipStream_t s);
+void launch_normals_tables(const TileDev* tiles, uint32_t first, uint32_t count, uint32_t w, uint32_t h, hipStream_t s);
+void launch_block_bounds(const TileDev* tiles, uint32_t first, uint32_t count, uint32_t w, uint32_t h, hipStream_t s);
 // interior normals of tiles[first .. first+count); also zeroes their border ring (fresh Rgba8Unorm texture)
 void launch_normals_interior(const TileDev* tiles, uint32_t first, uint32_t count, uint32_t w, uint32_t h, int lds_rows,
                              hipStream_t s);

@@ -86,6 +86,66 @@ __device__ __forceinline__ void vis_min(const Vis& v, size_t pix, uint64_t key) 
 struct SinCos64 { double s, c; };
 __device__ __forceinline__ SinCos64 sincos64(double a) { SinCos64 r; r.s = sin(a); r.c = cos(a); return r; }
 
+// The view-independent half of the cull for one raster block, in f64: the bounding sphere of the block's patch, the unit
+// directions of its four corners and the sagitta of the patch over their flat hull.  lo / la: sin/cos of the block's first and
+// last longitude / latitude, loc / lac: of its centre.
+__device__ __forceinline__ void block_bounds_store(double* bounds, uint32_t blocks_per_tile, uint32_t blk, float bmn, float bmx, const SinCos64 lo[2],
+                                                   const SinCos64 la[2], const SinCos64& loc, const SinCos64& lac) {
+    const double hmin = (double)bmn, hmax = (double)bmx, hmid = 0.5 * (hmin + hmax);
+    double* bs = bounds + (size_t)blk * 4;                                              // sphere
+    double* bb = bounds + (size_t)blocks_per_tile * 4 + (size_t)blk * 12;               // corner directions
+    double u[4][3];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const SinCos64 &o = lo[k & 1], &a = la[k >> 1];
+        u[k][0] = a.c * o.c; u[k][1] = a.c * o.s; u[k][2] = a.s;
+        bb[3 * k] = u[k][0]; bb[3 * k + 1] = u[k][1]; bb[3 * k + 2] = u[k][2];
+    }
+    const double Rm = (double)kR0 + hmid;
+    const double c[3] = {Rm * lac.c * loc.c, Rm * lac.c * loc.s, Rm * lac.s};
+    double r2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double dx = Rm * u[k][0] - c[0], dy = Rm * u[k][1] - c[1], dz = Rm * u[k][2] - c[2];
+        const double d2 = dx * dx + dy * dy + dz * dz;
+        r2 = d2 > r2 ? d2 : r2;
+    }
+    // every direction of the patch lies within the angular distance of the farthest corner from the centre direction,
+    // so the corners' chord distance bounds the sphere; + half the height range + margin
+    bs[0] = c[0]; bs[1] = c[1]; bs[2] = c[2];
+    bs[3] = sqrt(r2) + 0.5 * (hmax - hmin) + 8.0 + 64.0;
+    // How far the curved patch can stick out of the flat-faced hull of its eight slab corners (radially over the top
+    // face, sideways over the face along its equator-side parallel): at most the sagitta of the farthest corner's
+    // arc, R (1 - cos theta_max).  0.3 .. 0.7 m for a 60 x 15 cell block of a 1200-px tile, hundreds of metres for the
+    // blocks of a coarse tile: the occlusion filter pads its slab by this and only takes blocks where it is <= 1 m.
+    double dmin = 1.0;
+    const double uc[3] = {lac.c * loc.c, lac.c * loc.s, lac.s};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double d = u[k][0] * uc[0] + u[k][1] * uc[1] + u[k][2] * uc[2];
+        dmin = d < dmin ? d : dmin;
+    }
+    bounds[(size_t)blocks_per_tile * 16 + blk] = ((double)kR0 + (hmax > 0.0 ? hmax : 0.0) + 2.0) * (1.0 - dmin);
+}
+// The angles whose f64 sin/cos the bounds take: the latitude of vertex row vy / the longitude of vertex column vx (halves allowed).
+__device__ __forceinline__ double block_lat64(const TileDev& t, double vy) { return ((vy - (double)t.raster_y) * -(double)t.scale_y + (double)t.model_y) * 0.017453292519943295; }
+__device__ __forceinline__ double block_lon64(const TileDev& t, double vx) { return ((vx - (double)t.raster_x) * (double)t.scale_x + (double)t.model_x) * 0.017453292519943295; }
+// entries [start, start + stride, ...) of a tile's sin/cos tables (TileDev::trig_lon, trig_lat)
+__device__ __forceinline__ void trig_tables_fill(const TileDev& t, uint32_t w, uint32_t h, uint32_t start, uint32_t stride) {
+    for (uint32_t e = start; e < w + h; e += stride) {
+        float sn, cs;
+        if (e < w) {
+            sincos_f(vertex_lon(t, e), sn, cs);
+            const_cast<float*>(t.trig_lon)[2 * e] = sn;
+            const_cast<float*>(t.trig_lon)[2 * e + 1] = cs;
+        } else {
+            sincos_f(vertex_lat(t, e - w), sn, cs);
+            const_cast<float*>(t.trig_lat)[2 * (e - w)] = sn;
+            const_cast<float*>(t.trig_lat)[2 * (e - w) + 1] = cs;
+        }
+    }
+}
+
 // Per-tile tables of the frame phase, for a batch of tiles (blockIdx.y) in ONE launch: min/max height of the (kVX x kVY)
 // vertices of every raster block, the view-independent half of the cull (f64: the block's bounding sphere, the unit directions
 // of its four corners, the sagitta of its patch), and the tile's sin/cos tables (TileDev::trig_lon / trig_lat).
@@ -149,7 +209,6 @@ __global__ __launch_bounds__(256) void k_block_tables(const TileDev* __restrict_
             for (uint32_t k = 0; k < 4; ++k) { s_mn[wave][lane + 64 * k] = mn[k]; s_mx[wave][lane + 64 * k] = mx[k]; }
         }
         // ---- the f64 sin/cos pairs: lanes 0..2 latitudes (y0, y1, centre), lanes 3 + 3 b .. 5 + 3 b longitudes (x0, x1, centre) of block b
-        const double D2R = 0.017453292519943295;
         const double yy0 = (double)(by * kBCY);
         double yy1 = yy0 + (double)kBCY;
         if (yy1 > (double)(h - 1)) yy1 = (double)(h - 1);
@@ -157,14 +216,14 @@ __global__ __launch_bounds__(256) void k_block_tables(const TileDev* __restrict_
             double a;
             if (lane < 3u) {
                 const double vy = lane == 0 ? yy0 : (lane == 1 ? yy1 : 0.5 * (yy0 + yy1));
-                a = ((vy - (double)t.raster_y) * -(double)t.scale_y + (double)t.model_y) * D2R;
+                a = block_lat64(t, vy);
             } else {
                 const uint32_t b = (lane - 3u) / 3u, which = (lane - 3u) - 3u * b;
                 const double xx0 = (double)((bx0 + b) * kBCX);
                 double xx1 = xx0 + (double)kBCX;
                 if (xx1 > (double)(w - 1)) xx1 = (double)(w - 1);
                 const double vx = which == 0 ? xx0 : (which == 1 ? xx1 : 0.5 * (xx0 + xx1));
-                a = ((vx - (double)t.raster_x) * (double)t.scale_x + (double)t.model_x) * D2R;
+                a = block_lon64(t, vx);
             }
             const SinCos64 sc = sincos64(a);
             s_sc[wave][lane][0] = sc.s;
@@ -189,62 +248,61 @@ __global__ __launch_bounds__(256) void k_block_tables(const TileDev* __restrict_
             const uint32_t blk = by * bx_count + bx0 + lane;
             minmax[2 * blk] = bmn;
             minmax[2 * blk + 1] = bmx;
-            // the view-independent half of the cull, in f64: bounding sphere of the block's patch and its corner directions
-            const double hmin = (double)bmn, hmax = (double)bmx, hmid = 0.5 * (hmin + hmax);
             const double(*sc)[2] = s_sc[wave];
             const SinCos64 lo[2] = {{sc[3 + 3 * lane][0], sc[3 + 3 * lane][1]}, {sc[4 + 3 * lane][0], sc[4 + 3 * lane][1]}};
             const SinCos64 la[2] = {{sc[0][0], sc[0][1]}, {sc[1][0], sc[1][1]}};
             const SinCos64 loc = {sc[5 + 3 * lane][0], sc[5 + 3 * lane][1]}, lac = {sc[2][0], sc[2][1]};
-            double* bs = bounds + (size_t)blk * 4;                                              // sphere
-            double* bb = bounds + (size_t)blocks_per_tile * 4 + (size_t)blk * 12;               // corner directions
-            double u[4][3];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const SinCos64 &o = lo[k & 1], &a = la[k >> 1];
-                u[k][0] = a.c * o.c; u[k][1] = a.c * o.s; u[k][2] = a.s;
-                bb[3 * k] = u[k][0]; bb[3 * k + 1] = u[k][1]; bb[3 * k + 2] = u[k][2];
-            }
-            const double Rm = (double)kR0 + hmid;
-            const double c[3] = {Rm * lac.c * loc.c, Rm * lac.c * loc.s, Rm * lac.s};
-            double r2 = 0.0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const double dx = Rm * u[k][0] - c[0], dy = Rm * u[k][1] - c[1], dz = Rm * u[k][2] - c[2];
-                const double d2 = dx * dx + dy * dy + dz * dz;
-                r2 = d2 > r2 ? d2 : r2;
-            }
-            // every direction of the patch lies within the angular distance of the farthest corner from the centre direction,
-            // so the corners' chord distance bounds the sphere; + half the height range + margin
-            bs[0] = c[0]; bs[1] = c[1]; bs[2] = c[2];
-            bs[3] = sqrt(r2) + 0.5 * (hmax - hmin) + 8.0 + 64.0;
-            // How far the curved patch can stick out of the flat-faced hull of its eight slab corners (radially over the top
-            // face, sideways over the face along its equator-side parallel): at most the sagitta of the farthest corner's
-            // arc, R (1 - cos theta_max).  0.3 .. 0.7 m for a 60 x 15 cell block of a 1200-px tile, hundreds of metres for the
-            // blocks of a coarse tile: the occlusion filter pads its slab by this and only takes blocks where it is <= 1 m.
-            double dmin = 1.0;
-            const double uc[3] = {lac.c * loc.c, lac.c * loc.s, lac.s};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const double d = u[k][0] * uc[0] + u[k][1] * uc[1] + u[k][2] * uc[2];
-                dmin = d < dmin ? d : dmin;
-            }
-            bounds[(size_t)blocks_per_tile * 16 + blk] = ((double)kR0 + (hmax > 0.0 ? hmax : 0.0) + 2.0) * (1.0 - dmin);
+            block_bounds_store(bounds, blocks_per_tile, blk, bmn, bmx, lo, la, loc, lac);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // (the next run rewrites the strips)
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < w + h; e += gridDim.x * 256) {
-        float sn, cs;
-        if (e < w) {
-            sincos_f(vertex_lon(t, e), sn, cs);
-            const_cast<float*>(t.trig_lon)[2 * e] = sn;
-            const_cast<float*>(t.trig_lon)[2 * e + 1] = cs;
-        } else {
-            sincos_f(vertex_lat(t, e - w), sn, cs);
-            const_cast<float*>(t.trig_lat)[2 * (e - w)] = sn;
-            const_cast<float*>(t.trig_lat)[2 * (e - w) + 1] = cs;
-        }
+    trig_tables_fill(t, w, h, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
+}
+
+// The two halves of k_block_tables that do not read the DEM, for the load path whose normals pass collects the block minima /
+// maxima itself (k_normals_rolling<.., true>): the sin/cos tables BEFORE that pass (it reads cos(latitude) from them), the f64
+// bounds AFTER it (one lane per raster block, from the block's min/max).  Same expressions as k_block_tables, same results.
+__global__ __launch_bounds__(256) void k_trig_tables(const TileDev* __restrict__ tiles, uint32_t first, uint32_t w, uint32_t h) {
+    trig_tables_fill(tiles[first + blockIdx.y], w, h, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
+}
+// kLanes = 8: eight lanes per raster block -- lanes 0..5 of a group evaluate one f64 sin/cos pair each (first / last / centre
+// latitude, first / last / centre longitude), lane 0 collects them and finishes the block: a block's six sin/cos calls one after the
+// other on one lane are the whole latency of this kernel when a single tile is added (add_terrain: 0.43 -> 0.36 ms per tile).
+// kLanes = 1: one lane per block, for a batch of tiles, where the lanes are what counts (100 tiles: 0.239 against 0.251 ms for the
+// whole load phase).
+__device__ __forceinline__ double shfl_f64(double v, int src) {
+    return __hiloint2double(__shfl(__double2hiint(v), src), __shfl(__double2loint(v), src));
+}
+template <int kLanes>
+__global__ __launch_bounds__(256) void k_block_bounds(const TileDev* __restrict__ tiles, uint32_t first, uint32_t w, uint32_t h, uint32_t bx_count,
+                                                      uint32_t by_count) {
+    static_assert(kLanes == 1 || kLanes == 8, "");
+    const TileDev& t = tiles[first + blockIdx.y];
+    const uint32_t sub = kLanes == 8 ? threadIdx.x & 7u : 0u, blocks_per_tile = bx_count * by_count;
+    const uint32_t blk_raw = kLanes == 8 ? blockIdx.x * 32 + (threadIdx.x >> 3) : blockIdx.x * 256 + threadIdx.x;
+    const uint32_t blk = blk_raw < blocks_per_tile ? blk_raw : blocks_per_tile - 1;      // (surplus lanes redo the last block and store nothing)
+    const uint32_t by = blk / bx_count, bx = blk - by * bx_count;
+    const double yy0 = (double)(by * kBCY), xx0 = (double)(bx * kBCX);
+    double yy1 = yy0 + (double)kBCY, xx1 = xx0 + (double)kBCX;
+    if (yy1 > (double)(h - 1)) yy1 = (double)(h - 1);
+    if (xx1 > (double)(w - 1)) xx1 = (double)(w - 1);
+    SinCos64 g[6];      // latitudes of yy0, yy1, the centre; longitudes of xx0, xx1, the centre
+    if (kLanes == 8) {
+        // sub 0 1 2: the latitudes; sub 3 4 5: the longitudes (6, 7: idle copies of 5)
+        const double vy = sub == 0 ? yy0 : (sub == 1 ? yy1 : 0.5 * (yy0 + yy1)), vx = sub == 3 ? xx0 : (sub == 4 ? xx1 : 0.5 * (xx0 + xx1));
+        const SinCos64 mine = sincos64(sub < 3 ? block_lat64(t, vy) : block_lon64(t, vx));
+        const int base = (int)((threadIdx.x & 63u) & ~7u);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { g[k].s = shfl_f64(mine.s, base + k); g[k].c = shfl_f64(mine.c, base + k); }
+    } else {
+        g[0] = sincos64(block_lat64(t, yy0)); g[1] = sincos64(block_lat64(t, yy1)); g[2] = sincos64(block_lat64(t, 0.5 * (yy0 + yy1)));
+        g[3] = sincos64(block_lon64(t, xx0)); g[4] = sincos64(block_lon64(t, xx1)); g[5] = sincos64(block_lon64(t, 0.5 * (xx0 + xx1)));
+    }
+    if (sub == 0 && blk_raw < blocks_per_tile) {
+        const SinCos64 la[2] = {g[0], g[1]}, lo[2] = {g[3], g[4]};
+        block_bounds_store(const_cast<double*>(t.block_bounds), blocks_per_tile, blk, t.block_minmax[2 * blk], t.block_minmax[2 * blk + 1], lo, la, g[5], g[2]);
     }
 }
 
@@ -374,76 +432,120 @@ __device__ __forceinline__ float wave_from_left(float v, float first) {      // 
 __device__ __forceinline__ float wave_from_right(float v, float last) {      // lane i: lane i + 1's v; lane 63: `last`
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(last), __float_as_int(v), 0x130 /* wave_shl:1 */, 0xF, 0xF, false));
 }
-template <int kRollRows, int kWaves>
-__global__ __launch_bounds__(64 * kWaves) void k_normals_rolling(const TileDev* __restrict__ tiles, uint32_t first, uint32_t n_tiles, int W, int H) {
-    const uint32_t gx = ((uint32_t)W + 255u) / 256u, gy = (((uint32_t)H + kRollRows - 1u) / kRollRows + kWaves - 1u) / kWaves;
+// kTables: the pass also collects the min / max height of every raster block (TileDev::block_minmax) -- the one thing
+// k_block_tables reads the DEM for -- so that the load phase reads the DEM ONCE.  A strip is then 240 columns (four raster
+// blocks of kBCX = 60 cells; lanes 60..63 only feed lane 59's right neighbour) and a workgroup's waves share one block row
+// (kBCY = 15 rows: 4 + 4 + 4 + 3): a lane folds its four columns and its right neighbour's first one into one running minimum
+// and maximum per row (lanes 15 b .. 15 b + 14 then hold exactly the 61 vertex columns of block b), a wave adds the row below
+// its last one (the block's 16th vertex row for the last wave, a row of the same block for the others), the fifteen lanes of a
+// block are folded by four shuffles (1, 2, 4, 7: the windows overlap, which a minimum does not mind), the waves' partial
+// results meet in LDS.  Needs W % 240 == 0 (COP90: 1200, COP30: 3600); k_trig_tables runs before, k_block_bounds after.
+template <int kRollRows, int kWaves, bool kTables>
+__global__ __launch_bounds__(64 * kWaves) void k_normals_rolling(const TileDev* __restrict__ tiles, uint32_t first, uint32_t n_tiles, int W, int H,
+                                                                 uint32_t bx_count, uint32_t by_count) {
+    constexpr int kCols = kTables ? 4 * (int)kBCX : 256;                      // columns of a strip
+    constexpr int kChunkRows = kTables ? (int)kBCY : kRollRows * kWaves;      // rows of a workgroup
+    static_assert(!kTables || (kRollRows * kWaves >= (int)kBCY && kRollRows * (kWaves - 1) < (int)kBCY), "the waves of a workgroup cover one block row");
+    __shared__ float s_part[kTables ? kWaves : 1][4][2];
+    const uint32_t gx = ((uint32_t)W + kCols - 1u) / kCols, gy = ((uint32_t)H + kChunkRows - 1u) / kChunkRows;
     uint32_t piece;
-    if (!xcd_contiguous_piece(gx * gy * n_tiles, piece)) return;
+    if (!xcd_contiguous_piece(gx * gy * n_tiles, piece)) return;      // (workgroup-uniform: before any barrier)
     const uint32_t bz = piece / (gx * gy), by_ = (piece - bz * gx * gy) / gx, bx_ = piece - bz * gx * gy - by_ * gx;
     const TileDev& t = tiles[first + bz];
     const auto heights = TOPO_GLOBAL_F32(t.heights);
     const auto normals = TOPO_GLOBAL_U32_RW(t.normals);
     const auto trig_lat = TOPO_GLOBAL_F32(t.trig_lat);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int x0 = (int)bx_ * 256, c0 = x0 + 4 * lane;
-    const int y0 = ((int)by_ * kWaves + wave) * kRollRows;
-    if (y0 >= H) return;
-    const int y1 = y0 + kRollRows < H ? y0 + kRollRows : H;      // rows [y0, y1)
-    const bool col_active = c0 < W;                               // (W % 4 == 0: a lane's four columns are all inside or all outside)
-    const int cc = col_active ? c0 : W - 4;
+    const int x0 = (int)bx_ * kCols, c0 = x0 + 4 * lane;
+    const int y0 = (int)by_ * kChunkRows + wave * kRollRows;
+    const int y_end = ((int)by_ + 1) * kChunkRows < H ? ((int)by_ + 1) * kChunkRows : H;
+    if (!kTables && y0 >= H) return;
+    const int y1 = y0 + kRollRows < y_end ? y0 + kRollRows : y_end;      // rows [y0, y1)   (kTables: possibly none)
+    const bool col_active = c0 < W && c0 < x0 + kCols;            // (W % 4 == 0: a lane's four columns are all inside or all outside)
+    const int cc = c0 < W ? c0 : W - 4;
     // the two columns beside the strip, one load for both: lanes 0..31 the left one, lanes 32..63 the right one (clamped)
     const int ce = lane < 32 ? (x0 > 0 ? x0 - 1 : 0) : (x0 + 256 < W ? x0 + 256 : W - 1);
     auto row_ptr = [&](int y) { return heights + (size_t)(y < 0 ? 0 : (y > H - 1 ? H - 1 : y)) * W; };
     auto load4 = [&](int y) { return *(const __attribute__((address_space(1))) f32x4_t*)(row_ptr(y) + cc); };
     auto load_edge = [&](int y) { return row_ptr(y)[ce]; };
     const float xs = deg2rad(t.scale_x) * kR0, ys0 = deg2rad(t.scale_y) * kR0;
-    // rows y - 1 and y of the first output row, then four new rows per round
-    f32x4_t above = load4(y0 - 1), mid = load4(y0);
-    float mid_edge = load_edge(y0);
-    f32x4_t nx[4];
-    float ne[4];
+    float mn = INFINITY, mx = -INFINITY;      // kTables: the lane's columns 4 lane .. 4 lane + 4 over the wave's rows
+    if (!kTables || y0 < y1) {
+        // rows y - 1 and y of the first output row, then four new rows per round
+        f32x4_t above = load4(y0 - 1), mid = load4(y0);
+        float mid_edge = load_edge(y0);
+        f32x4_t nx[4];
+        float ne[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { nx[k] = load4(y0 + 1 + k); ne[k] = load_edge(y0 + 1 + k); }
-    auto out = normals + ((size_t)y0 * W + cc);
-    for (int y = y0; y < y1; y += 4) {
-        f32x4_t cur[4];
-        float ce4[4];
+        for (int k = 0; k < 4; ++k) { nx[k] = load4(y0 + 1 + k); ne[k] = load_edge(y0 + 1 + k); }
+        auto out = normals + ((size_t)y0 * W + cc);
+        for (int y = y0; y < y1; y += 4) {
+            f32x4_t cur[4];
+            float ce4[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { cur[k] = nx[k]; ce4[k] = ne[k]; }
-        if (y + 4 < y1) {      // (wave-uniform) the next round's rows: in flight under this round's arithmetic
+            for (int k = 0; k < 4; ++k) { cur[k] = nx[k]; ce4[k] = ne[k]; }
+            if (y + 4 < y1) {      // (wave-uniform) the next round's rows: in flight under this round's arithmetic
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { nx[k] = load4(y + 5 + k); ne[k] = load_edge(y + 5 + k); }
+                for (int k = 0; k < 4; ++k) { nx[k] = load4(y + 5 + k); ne[k] = load_edge(y + 5 + k); }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int gy = y + k;
+                if (gy >= y1) break;      // (wave-uniform)
+                const f32x4_t below = cur[k];
+                const float ys = ys0 * unif_first(trig_lat[2 * gy + 1]);
+                const float left_edge = unif2(mid_edge, 0), right_edge = unif2(mid_edge, 63);
+                const float hl = wave_from_left(mid.w, left_edge), hr = wave_from_right(mid.x, right_edge);
+                if (kTables) {
+                    mn = fminf(fminf(fminf(mn, mid.x), fminf(mid.y, mid.z)), fminf(mid.w, hr));
+                    mx = fmaxf(fmaxf(fmaxf(mx, mid.x), fmaxf(mid.y, mid.z)), fmaxf(mid.w, hr));
+                }
+                const bool row_in = gy >= 1 && gy < H - 1;
+                const float hL[4] = {hl, mid.x, mid.y, mid.z}, hR[4] = {mid.y, mid.z, mid.w, hr};
+                const float hT[4] = {above.x, above.y, above.z, above.w}, hB[4] = {below.x, below.y, below.z, below.w};
+                uint32_t tex[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int gx = c0 + q;
+                    const bool in = row_in && gx >= 1 && gx < W - 1;
+                    uint32_t v = 0;
+                    const bool settled = normal_texel_fast(xs, ys, hT[q], hL[q], hR[q], hB[q], v) || !in;
+                    if (!settled) v = normal_texel(xs, ys, hT[q], hL[q], hR[q], hB[q]);      // the guard band and non-finite heights: the full chain
+                    tex[q] = in ? v : 0u;
+                }
+                if (col_active) {
+                    u32x4_t o;
+                    o.x = tex[0]; o.y = tex[1]; o.z = tex[2]; o.w = tex[3];
+                    __builtin_nontemporal_store(o, (__attribute__((address_space(1))) u32x4_t*)(out));
+                }
+                out += W;
+                above = mid;
+                mid = below;
+                mid_edge = ce4[k];
+            }
         }
+        if (kTables) {      // the row below the wave's last one (row H - 1 again at the tile's end: the loads clamp)
+            const float hr = wave_from_right(mid.x, unif2(mid_edge, 63));
+            mn = fminf(fminf(fminf(mn, mid.x), fminf(mid.y, mid.z)), fminf(mid.w, hr));
+            mx = fmaxf(fmaxf(fmaxf(mx, mid.x), fmaxf(mid.y, mid.z)), fmaxf(mid.w, hr));
+        }
+    }
+    if (kTables) {
+        // lane 15 b: the minimum / maximum over lanes 15 b .. 15 b + 14 (the last window ends at lane 59)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int gy = y + k;
-            if (gy >= y1) break;      // (wave-uniform)
-            const f32x4_t below = cur[k];
-            const float ys = ys0 * unif_first(trig_lat[2 * gy + 1]);
-            const float left_edge = unif2(mid_edge, 0), right_edge = unif2(mid_edge, 63);
-            const float hl = wave_from_left(mid.w, left_edge), hr = wave_from_right(mid.x, right_edge);
-            const bool row_in = gy >= 1 && gy < H - 1;
-            const float hL[4] = {hl, mid.x, mid.y, mid.z}, hR[4] = {mid.y, mid.z, mid.w, hr};
-            const float hT[4] = {above.x, above.y, above.z, above.w}, hB[4] = {below.x, below.y, below.z, below.w};
-            uint32_t tex[4];
+        for (int sh = 1; sh <= 4; sh <<= 1) { mn = fminf(mn, __shfl_down(mn, sh)); mx = fmaxf(mx, __shfl_down(mx, sh)); }
+        mn = fminf(mn, __shfl_down(mn, 7));
+        mx = fmaxf(mx, __shfl_down(mx, 7));
+        if (lane < 60 && lane % 15 == 0) { s_part[wave][lane / 15][0] = mn; s_part[wave][lane / 15][1] = mx; }
+        __syncthreads();
+        if (threadIdx.x < 4u && by_ < by_count && 4u * bx_ + threadIdx.x < bx_count) {
+            float lo = s_part[0][threadIdx.x][0], hi = s_part[0][threadIdx.x][1];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int gx = c0 + q;
-                const bool in = row_in && gx >= 1 && gx < W - 1;
-                uint32_t v = 0;
-                const bool settled = normal_texel_fast(xs, ys, hT[q], hL[q], hR[q], hB[q], v) || !in;
-                if (!settled) v = normal_texel(xs, ys, hT[q], hL[q], hR[q], hB[q]);      // the guard band and non-finite heights: the full chain
-                tex[q] = in ? v : 0u;
-            }
-            if (col_active) {
-                u32x4_t o;
-                o.x = tex[0]; o.y = tex[1]; o.z = tex[2]; o.w = tex[3];
-                __builtin_nontemporal_store(o, (__attribute__((address_space(1))) u32x4_t*)(out));
-            }
-            out += W;
-            above = mid;
-            mid = below;
-            mid_edge = ce4[k];
+            for (int w2 = 1; w2 < kWaves; ++w2) { lo = fminf(lo, s_part[w2][threadIdx.x][0]); hi = fmaxf(hi, s_part[w2][threadIdx.x][1]); }
+            float* const minmax = const_cast<float*>(t.block_minmax);
+            const uint32_t blk = by_ * bx_count + 4u * bx_ + threadIdx.x;
+            minmax[2 * blk] = lo;
+            minmax[2 * blk + 1] = hi;
         }
     }
 }
@@ -1849,6 +1951,11 @@ __global__ void k_probe_div(int kind, const float* x, const float* y, float* out
              : kind == 4 ? __builtin_amdgcn_fractf(x[i])      // v_fract_f32, the instruction itself
              : kind == 5 ? fract_f(x[i])                       // the spec's fract as the kernels evaluate it
                          : sqrt_f(x[i]);
+    if (kind >= 6 && kind <= 8) {      // fs_main's dither (mode 0) of channel kind - 6 at p = (x, y), shading 0.25: the wave-level choice of the fraction's form
+        float c[4];
+        shade_fragment(0, f3{0.0f, 0.0f, 0.25f / 0.7f}, 0.0f, 0.0f, x[i], y[i], f3{0.0f, 0.0f, 0.0f}, f3{0.0f, 0.0f, 1.0f}, c);
+        out[i] = c[kind - 6];
+    }
 }
 
 }  // namespace
@@ -1864,6 +1971,28 @@ void launch_block_tables(const TileDev* tiles, uint32_t first, uint32_t count, u
     hipLaunchKernelGGL(k_block_tables, dim3((runs + 3) / 4, count), dim3(256), 0, s, tiles, first, w, h, bxc, byc);
 }
 
+// The load path that reads the DEM once (normals_tables_fused()): sin/cos tables -> normals + block minima / maxima -> f64 bounds.
+bool normals_tables_fused(uint32_t w, uint32_t h, int lds_rows) {
+    static const bool off = getenv("TOPO_LOAD_FUSED") && atoi(getenv("TOPO_LOAD_FUSED")) == 0;      // experiments: the separate kernels
+    return !off && lds_rows == 0 && w >= 4 * kBCX && w % (4 * kBCX) == 0 && h >= 3;
+}
+void launch_trig_tables(const TileDev* tiles, uint32_t first, uint32_t count, uint32_t w, uint32_t h, hipStream_t s) {
+    if (count == 0) return;
+    hipLaunchKernelGGL(k_trig_tables, dim3((w + h + 255) / 256, count), dim3(256), 0, s, tiles, first, w, h);
+}
+void launch_normals_tables(const TileDev* tiles, uint32_t first, uint32_t count, uint32_t w, uint32_t h, hipStream_t s) {
+    if (count == 0) return;
+    const uint32_t bxc = (w - 1 + kBCX - 1) / kBCX, byc = (h - 1 + kBCY - 1) / kBCY;
+    const uint32_t pieces = (w / (4 * kBCX)) * ((h + kBCY - 1) / kBCY) * count;
+    hipLaunchKernelGGL((k_normals_rolling<4, 4, true>), dim3(((pieces + 7) / 8) * 8), dim3(256), 0, s, tiles, first, count, (int)w, (int)h, bxc, byc);
+}
+void launch_block_bounds(const TileDev* tiles, uint32_t first, uint32_t count, uint32_t w, uint32_t h, hipStream_t s) {
+    if (count == 0) return;
+    const uint32_t bxc = (w - 1 + kBCX - 1) / kBCX, byc = (h - 1 + kBCY - 1) / kBCY;
+    if (count <= 4) hipLaunchKernelGGL(k_block_bounds<8>, dim3((bxc * byc + 31) / 32, count), dim3(256), 0, s, tiles, first, w, h, bxc, byc);      // latency
+    else hipLaunchKernelGGL(k_block_bounds<1>, dim3((bxc * byc + 255) / 256, count), dim3(256), 0, s, tiles, first, w, h, bxc, byc);               // throughput
+}
+
 void launch_normals_interior(const TileDev* tiles, uint32_t first, uint32_t count, uint32_t w, uint32_t h, int lds_rows,
                              hipStream_t s) {
     if (count == 0) return;
@@ -1874,7 +2003,7 @@ void launch_normals_interior(const TileDev* tiles, uint32_t first, uint32_t coun
         // 0.225-0.233.  Short-lived single-wave workgroups stream best (a plain 16-byte copy of the same bytes: 6.3 TB/s as one
         // load and one store per thread, 5.0-5.3 as a grid-stride loop: tools/calib.hip copy).  TOPO_ROLL_SHAPE = rows * 10 + waves.
         static const int shape = getenv("TOPO_ROLL_SHAPE") ? atoi(getenv("TOPO_ROLL_SHAPE")) : 41;
-#define TOPO_ROLL(R, WV) hipLaunchKernelGGL((k_normals_rolling<R, WV>), dim3(((((w + 255) / 256) * (((h + (R)-1) / (R) + (WV)-1) / (WV)) * count + 7) / 8) * 8), dim3(64 * (WV)), 0, s, tiles, first, count, (int)w, (int)h)
+#define TOPO_ROLL(R, WV) hipLaunchKernelGGL((k_normals_rolling<R, WV, false>), dim3(((((w + 255) / 256) * (((h + (R)-1) / (R) + (WV)-1) / (WV)) * count + 7) / 8) * 8), dim3(64 * (WV)), 0, s, tiles, first, count, (int)w, (int)h, 0u, 0u)
         switch (shape) {
             case 44: TOPO_ROLL(4, 4); break;
             case 81: TOPO_ROLL(8, 1); break;

@@ -322,13 +322,41 @@ TOPO_HD bool normal_texel_fast(float x, float y, float hT, float hL, float hR, f
 }
 
 // ---- fragment shading (render_shader.wgsl:75-115) ------------------------------------------------
-TOPO_HD float hash12n(float sx, float sy) {
-    float px = fract_f(sx * 5.3987f);
-    float py = fract_f(sy * 5.4421f);
+// fract(x) = x - floor(x).  The device's v_fract_f32 returns that very value for every f32 x -- NaN and the infinities
+// included -- EXCEPT the negatives above -2^-24, where the difference rounds to 1.0 and the instruction returns the largest
+// float below 1 (tools/exp_fract_probe.py: all 2^32 inputs; tests/test_gpu_parity.py::test_fract_probe).  kInstr selects the
+// instruction (one issue slot for two); the caller has to know that x is not such a negative.
+template <bool kInstr>
+TOPO_HD float fract_t(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (kInstr) return __builtin_amdgcn_fractf(x);
+#endif
+    return x - floorf(x);
+}
+// kFirstInstr: the two fractions of the (scaled) inputs may use the instruction.  The third one always may: its operand is a
+// product of numbers that are >= 0 (px, py in [0, 1], d >= 0) or NaN.
+template <bool kFirstInstr>
+TOPO_HD float hash12n_t(float sx, float sy) {
+    float px = fract_t<kFirstInstr>(sx * 5.3987f);
+    float py = fract_t<kFirstInstr>(sy * 5.4421f);
     const float d = py * (px + 21.5351f) + px * (py + 14.3137f);
     px += d;
     py += d;
-    return fract_f(px * py * 95.4307f);
+    return fract_t<true>(px * py * 95.4307f);
+}
+TOPO_HD float hash12n(float sx, float sy) { return hash12n_t<false>(sx, sy); }
+
+// ditherRGB's six hashes at p = (px, py): out[k] = lin + (hash42n(p)_k + hash42n(p + 0.13)_k - 1) / 255
+template <bool kFirstInstr>
+TOPO_HD void dither_rgb(float px, float py, float lin, float out[4]) {
+    const float qx = px + 0.13f, qy = py + 0.13f;
+    const float off[3] = {0.0f, 0.07f, 0.11f};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float h1 = k == 0 ? hash12n_t<kFirstInstr>(px, py) : hash12n_t<kFirstInstr>(px + off[k], py + off[k]);
+        const float h2 = k == 0 ? hash12n_t<kFirstInstr>(qx, qy) : hash12n_t<kFirstInstr>(qx + off[k], qy + off[k]);
+        out[k] = lin + div_const(1.0f * (h1 + h2 - 1.0f), 255.0f, 1.0f / 255.0f);
+    }
 }
 
 // Linear colour of fs_main for one fragment.  frag = pixel centre, cam = camera_pos.xy.
@@ -349,14 +377,19 @@ TOPO_HD void shade_fragment(int view_mode, f3 sun, float cam_x, float cam_y, flo
         return;
     }
     const float px = frag_x + cam_x - wpos.x, py = frag_y + cam_y - wpos.y;
-    const float qx = px + 0.13f, qy = py + 0.13f;
-    const float off[3] = {0.0f, 0.07f, 0.11f};
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const float h1 = k == 0 ? hash12n(px, py) : hash12n(px + off[k], py + off[k]);
-        const float h2 = k == 0 ? hash12n(qx, qy) : hash12n(qx + off[k], qy + off[k]);
-        out[k] = lin + div_const(1.0f * (h1 + h2 - 1.0f), 255.0f, 1.0f / 255.0f);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(TOPO_EXP_SPEC_FRACT)      // (experiment build TOPO_EXP_SPEC_FRACT: the two-instruction form everywhere)
+    // The twelve first-level fractions take (p + c) * m with c in {0, 0.07, 0.11, 0.13, 0.13 + 0.07, 0.13 + 0.11} and m > 5: such
+    // an operand is a negative above -2^-24 only if p + c lies in (-1.2e-8, 0), i.e. p within 2e-8 of -c, and every -c lies in
+    // [-0.25, 0].  So a pixel with neither coordinate in [-0.3, 0] may use the instruction throughout (18 issue slots for 36);
+    // the wave takes the two-instruction form when any of its pixels is in the window (p is a distance of hundreds of metres
+    // to hundreds of kilometres: about one row of 64 pixels in 200).  A NaN coordinate fails the test -- and is NaN in both forms.
+    const bool window = fminf(fabsf(px + 0.15f), fabsf(py + 0.15f)) <= 0.15f;
+    if (__builtin_amdgcn_ballot_w64(window) == 0ull) {
+        dither_rgb<true>(px, py, lin, out);
+        return;
     }
+#endif
+    dither_rgb<false>(px, py, lin, out);
 }
 
 // ---- post pass (postprocessing_shader.wgsl:68-96) -------------------------------------------------
