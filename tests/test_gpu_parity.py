@@ -593,7 +593,7 @@ def test_full_size_config4_sectors_against_oracle(topo, orc):
     c_off = g.counters()
     assert np.array_equal(rg, rg0) and np.array_equal(dg.view(np.uint32), dg0.view(np.uint32))
     assert c_on["far_tested"] > 10 * c_on["far_survived"] and c_off["far_tested"] == 0
-    assert c_on["blocks_rastered"] < c_off["blocks_rastered"] // 4
+    assert c_on["blocks_rastered"] < c_off["blocks_rastered"] // 2      # (with the filter on the count is in strips of 2 cell rows: up to 8 per block)
     o.update(sw, sh, pick[0], topo.post_uniforms(sw, sh))
     ro, do = o.render_views(pick, threads=2)
     for k in range(2):

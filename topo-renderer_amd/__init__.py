@@ -535,7 +535,7 @@ class TerrainRenderer:
         out = np.zeros(6, np.uint32)
         self._check(lib().topo_get_counters(self._h, _p(out)))
         return {"blocks_rastered": int(out[0]) + int(out[5]), "big_items": int(out[1]), "status": int(out[2]), "rare_items": int(out[3]),
-                "near_blocks": int(out[0]), "far_tested": int(out[4]), "far_survived": int(out[5])}   # near/survivors: in 4-row strips
+                "near_blocks": int(out[0]), "far_tested": int(out[4]), "far_survived": int(out[5])}   # near/survivors: in strips of 1 or 2 cell rows (terrain_renderer.cpp: near_strip)
 
     def set_timing_slots(self, names=None):
         """Measure only the named per-kernel durations (TIMING_NAMES[:6]); None = all, () = just the total."""

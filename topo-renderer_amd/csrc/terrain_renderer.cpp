@@ -431,7 +431,13 @@ int TerrainRenderer::render_frame(FrameCtx& c, hipStream_t stream, uint32_t n, c
         TOPO_HIP_TRY(hipMemsetAsync(c.d_dirty, 1, c.cap_dirty, stream));
     }
     if (int rc = ensure(&d_views_, &cap_views_, sizeof(ViewDev) * kMaxViewsPerSlot * kViewSlots)) return rc;
-    const size_t near_cap = 8 * work_cap;   // a near block is cut into strips of >= 2 cell rows: at most 8
+    // A near block (and a far survivor) is cut into strips of near_strip cell rows, one wave each: the raster phase is as long
+    // as its longest strip, and a strip's vertex rows cost less than the pixels of its triangles.  Measured (tools/exp_strip.sh,
+    // ms per frame at 1 / 2 / 4 rows): c1 0.146 / 0.148 / 0.157, c2 0.186 / 0.184 / 0.194, c3 0.382 / 0.372 / 0.390,
+    // c4 0.964 / 0.933 / 0.942.  TOPO_NEAR_STRIP overrides (experiments).
+    static const int strip_env = getenv("TOPO_NEAR_STRIP") ? atoi(getenv("TOPO_NEAR_STRIP")) : 0;
+    const uint32_t near_strip = strip_env >= 1 && strip_env <= 15 ? (uint32_t)strip_env : (work_cap <= 64 * 1024 ? 1u : 2u);
+    const size_t near_cap = (size_t)((kBCY + near_strip - 1) / near_strip) * work_cap;
     if (int rc = ensure_on(stream, &c.d_work, &c.cap_work, (near_cap ? near_cap : 1) * sizeof(WorkItem))) return rc;
     if (int rc = ensure_on(stream, &c.d_work2, &c.cap_work2, (near_cap ? near_cap : 1) * sizeof(WorkItem))) return rc;   // far survivors, in strips too
     // the far-candidate list: kFarLists sub-lists, cull workgroup b (256 blocks) appending to sub-list b % kFarLists
@@ -488,6 +494,7 @@ int TerrainRenderer::render_frame(FrameCtx& c, hipStream_t stream, uint32_t n, c
     p.work_cap = (uint32_t)work_cap;
     p.far_sub_cap = (uint32_t)far_sub_cap;
     p.near_cap = (uint32_t)near_cap;
+    p.near_strip = near_strip;
     p.big_cap = (uint32_t)big_cap;
     p.n_views = n;
     p.n_tiles = n_tiles;

@@ -57,7 +57,8 @@ struct FrameParams {
     WorkItem* work2;           // far survivors (k_occlusion -> second k_raster)
     uint32_t work_cap, big_cap, rare_cap;   // work_cap: entries of work2 (one per block and view)
     uint32_t far_sub_cap;                   // entries of each of the kFarLists sub-lists of `far` (enough for every candidate its workgroups can produce)
-    uint32_t near_cap;                      // entries of work (up to 4 strips per near block)
+    uint32_t near_cap;                      // entries of work / work2 (ceil(15 / near_strip) strips per block)
+    uint32_t near_strip;                    // cell rows per strip of a near block / far survivor (1 .. 15)
     float split_m;             // view depth (m) beyond which a block is an occlusion-test candidate; 0 = feature off
     uint32_t n_views, n_tiles;
     int32_t W, H;

@@ -440,7 +440,7 @@ __device__ __forceinline__ float wave_from_right(float v, float last) {      // 
 // its last one (the block's 16th vertex row for the last wave, a row of the same block for the others), the fifteen lanes of a
 // block are folded by four shuffles (1, 2, 4, 7: the windows overlap, which a minimum does not mind), the waves' partial
 // results meet in LDS.  Needs W % 240 == 0 (COP90: 1200, COP30: 3600); k_trig_tables runs before, k_block_bounds after.
-template <int kRollRows, int kWaves, bool kTables>
+template <int kRollRows, int kWaves, bool kTables, int kBatch = 4>      // kBatch: rows loaded per round
 __global__ __launch_bounds__(64 * kWaves) void k_normals_rolling(const TileDev* __restrict__ tiles, uint32_t first, uint32_t n_tiles, int W, int H,
                                                                  uint32_t bx_count, uint32_t by_count) {
     constexpr int kCols = kTables ? 4 * (int)kBCX : 256;                      // columns of a strip
@@ -474,22 +474,22 @@ __global__ __launch_bounds__(64 * kWaves) void k_normals_rolling(const TileDev* 
         // rows y - 1 and y of the first output row, then four new rows per round
         f32x4_t above = load4(y0 - 1), mid = load4(y0);
         float mid_edge = load_edge(y0);
-        f32x4_t nx[4];
-        float ne[4];
+        f32x4_t nx[kBatch];
+        float ne[kBatch];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { nx[k] = load4(y0 + 1 + k); ne[k] = load_edge(y0 + 1 + k); }
+        for (int k = 0; k < kBatch; ++k) { nx[k] = load4(y0 + 1 + k); ne[k] = load_edge(y0 + 1 + k); }
         auto out = normals + ((size_t)y0 * W + cc);
-        for (int y = y0; y < y1; y += 4) {
-            f32x4_t cur[4];
-            float ce4[4];
+        for (int y = y0; y < y1; y += kBatch) {
+            f32x4_t cur[kBatch];
+            float ce4[kBatch];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { cur[k] = nx[k]; ce4[k] = ne[k]; }
-            if (y + 4 < y1) {      // (wave-uniform) the next round's rows: in flight under this round's arithmetic
+            for (int k = 0; k < kBatch; ++k) { cur[k] = nx[k]; ce4[k] = ne[k]; }
+            if (y + kBatch < y1) {      // (wave-uniform) the next round's rows: in flight under this round's arithmetic
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { nx[k] = load4(y + 5 + k); ne[k] = load_edge(y + 5 + k); }
+                for (int k = 0; k < kBatch; ++k) { nx[k] = load4(y + kBatch + 1 + k); ne[k] = load_edge(y + kBatch + 1 + k); }
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < kBatch; ++k) {
                 const int gy = y + k;
                 if (gy >= y1) break;      // (wave-uniform)
                 const f32x4_t below = cur[k];
@@ -645,10 +645,6 @@ __global__ __launch_bounds__(256) void k_clear(uint64_t* __restrict__ vis, uint8
 // Conservative frustum test of one raster block against one view, in f64.  A block is kept unless its
 // bounding sphere (inflated by 64 m for the f32 noise of the real vertex path) lies wholly outside one of
 // the six clip planes of camera_proj.  Culling is result-neutral: culled blocks cannot produce fragments.
-#ifndef TOPO_NEAR_STRIP
-#define TOPO_NEAR_STRIP 4
-#endif
-constexpr uint32_t kStrip = TOPO_NEAR_STRIP;      // cell rows per near-block strip (terrain_renderer.cpp sizes the list for >= 2)
 
 // Clip plane `pl` of a column-major view-projection matrix as (a, b, c, d, |(a, b, c)|): 0..3 = w +- x, w +- y,
 // 4 = near (z_clip >= 0), 5 = w - z.
@@ -679,17 +675,17 @@ __device__ __forceinline__ void clip_plane(const float* m, int pl, double out[5]
 //    < 0.001 px beyond the split distance) and a lower bound of the depths
 //    (z_ndc at the smallest corner w, minus 8/w: the f32 clip-space cancellation noise is ~1 clip unit).
 // Emit a block the raster must visit.  With the occlusion filter on, such blocks are few and heavy (large triangles),
-// so each is cut into strips of kStrip cell rows to spread them over the resident waves:
+// so each is cut into strips of P.near_strip cell rows (the host picks 1, 2 or 4 by the size of the submission) to spread them over the resident waves:
 // block = id | first cell row << 24 | rows << 28 (rows 0 = the whole block).
 __device__ __forceinline__ void emit_near(const FrameParams& P, uint32_t view, uint32_t rank, uint32_t blk) {
     if (P.split_m > 0.0f) {
         const uint32_t by = blk / P.bx_count;
         const uint32_t cell_rows = min(kBCY, P.tile_h - 1 - by * kBCY);
-        const uint32_t n = (cell_rows + kStrip - 1) / kStrip;
+        const uint32_t strip = P.near_strip, n = (cell_rows + strip - 1) / strip;
         const uint32_t base = atomicAdd(&P.counters[0], n);
         for (uint32_t k = 0; k < n; ++k)
-            if (base + k < P.near_cap && TOPO_CHK(P.counters, blk < (1u << 24) && kStrip * k < 16u, 4u, blk))
-                P.work[base + k] = WorkItem{(view << 16) | rank, blk | ((kStrip * k) << 24) | (min(kStrip, cell_rows - kStrip * k) << 28)};
+            if (base + k < P.near_cap && TOPO_CHK(P.counters, blk < (1u << 24) && strip * k < 16u, 4u, blk))
+                P.work[base + k] = WorkItem{(view << 16) | rank, blk | ((strip * k) << 24) | (min(strip, cell_rows - strip * k) << 28)};
         return;
     }
     const uint32_t slot = atomicAdd(&P.counters[0], 1u);
@@ -859,11 +855,11 @@ __global__ __launch_bounds__(256) void k_occlusion(FrameParams P) {
             // fraction of the resident waves
             const uint32_t blk = fi.block, by = blk / P.bx_count;
             const uint32_t cell_rows = min(kBCY, P.tile_h - 1 - by * kBCY);
-            const uint32_t n = (cell_rows + kStrip - 1) / kStrip;
+            const uint32_t strip = P.near_strip, n = (cell_rows + strip - 1) / strip;
             const uint32_t base = atomicAdd(&P.counters[5], n);
             for (uint32_t k = 0; k < n; ++k)
                 if (base + k < P.near_cap)
-                    P.work2[base + k] = WorkItem{fi.view_rank, blk | ((kStrip * k) << 24) | (min(kStrip, cell_rows - kStrip * k) << 28)};
+                    P.work2[base + k] = WorkItem{fi.view_rank, blk | ((strip * k) << 24) | (min(strip, cell_rows - strip * k) << 28)};
         }
     }
 }
@@ -1984,7 +1980,16 @@ void launch_normals_tables(const TileDev* tiles, uint32_t first, uint32_t count,
     if (count == 0) return;
     const uint32_t bxc = (w - 1 + kBCX - 1) / kBCX, byc = (h - 1 + kBCY - 1) / kBCY;
     const uint32_t pieces = (w / (4 * kBCX)) * ((h + kBCY - 1) / kBCY) * count;
-    hipLaunchKernelGGL((k_normals_rolling<4, 4, true>), dim3(((pieces + 7) / 8) * 8), dim3(256), 0, s, tiles, first, count, (int)w, (int)h, bxc, byc);
+    // rows per wave x waves of the 15-row workgroup (TOPO_FUSED_SHAPE = rows * 10 + waves; a wave's rows are loaded in one round)
+    static const int shape = getenv("TOPO_FUSED_SHAPE") ? atoi(getenv("TOPO_FUSED_SHAPE")) : 44;
+    const dim3 grid(((pieces + 7) / 8) * 8);
+    switch (shape) {
+        case 53: hipLaunchKernelGGL((k_normals_rolling<5, 3, true, 5>), grid, dim3(192), 0, s, tiles, first, count, (int)w, (int)h, bxc, byc); break;
+        case 35: hipLaunchKernelGGL((k_normals_rolling<3, 5, true, 3>), grid, dim3(320), 0, s, tiles, first, count, (int)w, (int)h, bxc, byc); break;
+        case 82: hipLaunchKernelGGL((k_normals_rolling<8, 2, true, 4>), grid, dim3(128), 0, s, tiles, first, count, (int)w, (int)h, bxc, byc); break;
+        case 151: hipLaunchKernelGGL((k_normals_rolling<15, 1, true, 5>), grid, dim3(64), 0, s, tiles, first, count, (int)w, (int)h, bxc, byc); break;
+        default: hipLaunchKernelGGL((k_normals_rolling<4, 4, true, 4>), grid, dim3(256), 0, s, tiles, first, count, (int)w, (int)h, bxc, byc); break;
+    }
 }
 void launch_block_bounds(const TileDev* tiles, uint32_t first, uint32_t count, uint32_t w, uint32_t h, hipStream_t s) {
     if (count == 0) return;
