@@ -73,7 +73,7 @@ def _worker(rank, world, port, expect_path, out_q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2])
+@pytest.mark.parametrize("world", [2, 4])
 def test_sector_sharding_allgather_gloo(tmp_path, world):
     sys.path.insert(0, ROOT)
     import topo_renderer_amd as T

@@ -1159,6 +1159,37 @@ def test_occlusion_filter_is_conservative_on_coarse_tiles(topo, orc, tile, n, sp
         assert tested > 0           # 720-px tiles: 0.95 m -- filtered, with the sagitta added to the slab
 
 
+def test_two_rank_panorama_over_rccl(topo, tmp_path):
+    """The N > 1 half of the C-ABI panorama path on real hardware: two processes, two GPUs, RCCL bound by libtopo_hip.so itself
+    (topo_comm_unique_id / topo_comm_init), the frame resolved slot by slot with each slot's exchange under the next slot's
+    resolve.  Every rank must end up with the strip a world of one renders.  Skipped on a box with fewer than two GPUs."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "two_rank_worker.py")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, worker, str(rk), str(tmp_path)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for rk in (0, 1)]
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out)
+    assert all(p.returncode == 0 for p in procs), outs
+    sc = Scene(96, 2, 2, eye_dh=120.0)
+    sw, sh = 96, 160
+    g = topo.TerrainRenderer(sw, sh)
+    sc.load(g)
+    ra, _ = _strip(topo, g, sc.panorama(sw, sh, yaw0_deg=25.0), sw, sh)
+    for rk in (0, 1):
+        assert np.array_equal(np.load(os.path.join(str(tmp_path), f"strip{rk}.npy")), ra), f"rank {rk}'s strip differs from the world-of-one strip"
+
+
 def test_panorama_and_batch_entry_points(topo, orc):
     """topo_render_panorama (world of one: all 8 sectors, no collective) and topo_render_batch -- the multi-GPU entry points of
     the C ABI -- produce what topo_render_views_device produces from the same cameras; one sector and one batch viewpoint
