@@ -1597,7 +1597,7 @@ __global__ __launch_bounds__(256, TOPO_RESOLVE_WGS) void k_resolve(FrameParams P
                         const uint32_t draw = id >> 1, fan = id & 1u;
                         const uint32_t rank = fastdiv(draw, P.div_tris), tri = draw - rank * P.tris_per_tile;
                         TriRecord rec;
-                        if (TOPO_CHK(P.counters, rank < P.n_tiles, 13u, id)) resolve_setup(P.tiles[rank], P.tile_w, P.div_hm1, P.tile_h - 1, view, P.W, P.H, tri, fan, s_ndec, B.bx, y0, rec);
+                        if (TOPO_CHK(P.counters, rank < P.n_tiles, 13u, id)) resolve_setup<true>(P.tiles[rank], P.tile_w, P.div_hm1, P.tile_h - 1, view, P.W, P.H, tri, fan, s_ndec, B.bx, y0, rec);
                         else rec = TriRecord{};
                         int k = 0;
 #define TOPO_X(f) s_rec[wave][k++][lane] = rec.f;
@@ -1647,7 +1647,7 @@ __global__ __launch_bounds__(256, TOPO_RESOLVE_WGS) void k_resolve(FrameParams P
                             const uint32_t draw = sel >> 1, fan = sel & 1u;
                             const uint32_t rank = fastdiv(draw, P.div_tris), tri = draw - rank * P.tris_per_tile;
                             ok = TOPO_CHK(P.counters, rank < P.n_tiles, 13u, sel) &&
-                                 resolve_varyings(P.tiles[rank], P.tile_w, P.div_hm1, P.tile_h - 1, view, P.W, P.H, tri, fan, s_ndec, px, py, wpos, wnrm);
+                                 resolve_varyings<true>(P.tiles[rank], P.tile_w, P.div_hm1, P.tile_h - 1, view, P.W, P.H, tri, fan, s_ndec, px, py, wpos, wnrm);
                         }
                         if (ok) shade_fragment(view_mode, sun, cam_x, cam_y, (float)px + 0.5f, (float)py + 0.5f, wpos, wnrm, lin);
                         c8 = (kSrgb ? srgb_encode_lut3(s_thresh, lut, lin[0], lin[1], lin[2]) : to_unorm8(lin[0]) | (to_unorm8(lin[1]) << 8) | (to_unorm8(lin[2]) << 16)) |

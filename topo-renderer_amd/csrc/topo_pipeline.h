@@ -71,10 +71,14 @@ TOPO_HD f3 vertex_world(const TileDev& t, uint32_t vx, uint32_t vy, float height
 // 2 * (c / 255) - 1: the shader's decode of one normal channel.  `ndec`, when given, is that function tabulated for
 // c = 0..255 (k_resolve keeps it in LDS: one lookup instead of six instructions per channel).
 TOPO_HD float normal_channel(uint32_t c) { return 2.0f * from_unorm8(c) - 1.0f; }
+// kTableOnly: the caller vouches for `ndec` (k_resolve: its LDS table) -- otherwise the compiler, which cannot prove a pointer into
+// LDS non-null, puts a test and a branch in front of every one of the nine lookups of a record pass, each with its own wait.
+template <bool kTableOnly = false>
 TOPO_HD f3 vertex_normal(const TileDev& t, uint32_t packed, const float* ndec = nullptr) {
-    const float nx = ndec ? ndec[packed & 255u] : normal_channel(packed & 255u);
-    const float ny = ndec ? ndec[(packed >> 8) & 255u] : normal_channel((packed >> 8) & 255u);
-    const float nz = ndec ? ndec[(packed >> 16) & 255u] : normal_channel((packed >> 16) & 255u);
+    const bool table = kTableOnly || ndec != nullptr;
+    const float nx = table ? ndec[packed & 255u] : normal_channel(packed & 255u);
+    const float ny = table ? ndec[(packed >> 8) & 255u] : normal_channel((packed >> 8) & 255u);
+    const float nz = table ? ndec[(packed >> 16) & 255u] : normal_channel((packed >> 16) & 255u);
     const float* m = t.rot;   // mat * vec4(n, 0): fma chain, the zero w column drops out
     return {fmaf(m[6], nz, fmaf(m[3], ny, m[0] * nx)), fmaf(m[7], nz, fmaf(m[4], ny, m[1] * nx)),
             fmaf(m[8], nz, fmaf(m[5], ny, m[2] * nx))};
@@ -541,7 +545,7 @@ struct ResolvedTri {
 // kShading (the resolve pass): a primitive cut by the near plane is not clipped -- its varyings come from its own three
 // vertices (homogeneous_weights) -- so the function returns false with `cut` set and r.v[] holding those vertices.
 // Without kShading (k_raster_rare: coverage and depth) the piece `fan` of the clipped polygon is produced.
-template <bool kShading = false>
+template <bool kShading = false, bool kTableOnly = false>
 TOPO_HD bool resolve_vertices(const TileDev& t, uint32_t tile_w, FastDiv div_hm1, uint32_t hm1, const ViewDev& view, int32_t W, int32_t H,
                               uint32_t tri, uint32_t fan, const float* ndec, ResolvedTri& r, bool* cut = nullptr) {
     // the triangle's three vertices are corners of one grid cell: two distinct longitudes, two distinct latitudes,
@@ -569,7 +573,7 @@ TOPO_HD bool resolve_vertices(const TileDev& t, uint32_t tile_w, FastDiv div_hm1
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
         r.v[q].wpos = world_from_sincos(hq[q], oy[q] ? sla1 : sla0, oy[q] ? cla1 : cla0, ox[q] ? slo1 : slo0, ox[q] ? clo1 : clo0);
-        r.v[q].wnrm = vertex_normal(t, nq[q], ndec);
+        r.v[q].wnrm = vertex_normal<kTableOnly>(t, nq[q], ndec);
         mat4_point(view.proj, r.v[q].wpos.x, r.v[q].wpos.y, r.v[q].wpos.z, r.v[q].clip);
     }
     const bool all_in = r.v[0].clip[2] >= 0.0f && r.v[1].clip[2] >= 0.0f && r.v[2].clip[2] >= 0.0f;
@@ -595,12 +599,13 @@ TOPO_HD bool resolve_triangle(const TileDev& t, uint32_t tile_w, FastDiv div_hm1
 }
 
 // Varyings of the fragment at pixel (px, py) whose winner is triangle `tri` (piece `fan`) of tile t: what fs_main receives.
+template <bool kTableOnly = false>
 TOPO_HD bool resolve_varyings(const TileDev& t, uint32_t tile_w, FastDiv div_hm1, uint32_t hm1, const ViewDev& view, int32_t W, int32_t H,
                               uint32_t tri, uint32_t fan, const float* ndec, int32_t px, int32_t py, f3& wpos, f3& wnrm) {
     ResolvedTri r;
     bool cut = false;
     float q[3];
-    if (resolve_vertices<true>(t, tile_w, div_hm1, hm1, view, W, H, tri, fan, ndec, r, &cut)) {
+    if (resolve_vertices<true, kTableOnly>(t, tile_w, div_hm1, hm1, view, W, H, tri, fan, ndec, r, &cut)) {
         float b[3];
         if (fan != 0 || !triangle_bary(r.s[0], r.s[1], r.s[2], px, py, b)) return false;
         q[0] = b[0] * div_f(1.0f, r.v[0].clip[3]); q[1] = b[1] * div_f(1.0f, r.v[1].clip[3]); q[2] = b[2] * div_f(1.0f, r.v[2].clip[3]);
@@ -681,13 +686,14 @@ TOPO_HD uint32_t f64_hi(double d) {
 // will be asked about (k_resolve: the origin of the wave's strip).
 // (Every word is a local that is assigned on every path and stored once at the end: a struct that is zeroed first and
 // overwritten in the branches ends up in scratch memory.)
+template <bool kTableOnly = false>
 TOPO_HD void resolve_setup(const TileDev& t, uint32_t tile_w, FastDiv div_hm1, uint32_t hm1, const ViewDev& view, int32_t W, int32_t H,
                            uint32_t tri, uint32_t fan, const float* ndec, int32_t ox, int32_t oy, TriRecord& rec) {
     ResolvedTri r;
     bool cut = false;
     uint32_t kind = 0, iw0 = 0, iw1 = 0, iw2 = 0, iA = 0;
     uint32_t u0 = 0, u1 = 0, u2 = 0, u3 = 0, u4 = 0, u5 = 0, u6 = 0, u7 = 0, u8 = 0, u9 = 0, u10 = 0, u11 = 0, u12 = 0, u13 = 0;
-    if (resolve_vertices<true>(t, tile_w, div_hm1, hm1, view, W, H, tri, fan, ndec, r, &cut)) {
+    if (resolve_vertices<true, kTableOnly>(t, tile_w, div_hm1, hm1, view, W, H, tri, fan, ndec, r, &cut)) {
         const int32_t X0 = r.s[0].X, Y0 = r.s[0].Y, X1 = r.s[1].X, Y1 = r.s[1].Y, X2 = r.s[2].X, Y2 = r.s[2].Y;
         const int64_t area2 = (int64_t)(X1 - X0) * (Y2 - Y0) - (int64_t)(Y1 - Y0) * (X2 - X0);
         if (fan == 0 && area2 < 0) {
