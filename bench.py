@@ -315,7 +315,9 @@ def main():
         "per_kernel": per_kernel,
         "kernel_ms": {k: round(v, 4) for k, v in kernel_ms.items()},
         "kernel_ms_note": f"'{dom}' and 'total': HIP events in the timed region (only those events are recorded there); the other "
-                          f"kernels: medians of a separate pass of {n_detail} frames with all timing events on (total then {round(detail['total'], 4)} ms)",
+                          f"kernels: medians of a separate pass of {n_detail} frames with all timing events on (total then {round(detail['total'], 4)} ms); "
+                          "'clear' = k_clear_cull, the visibility clear and the cull side by side in one launch ('cull' = the empty event gap behind it; "
+                          "TOPO_FUSE_CLEAR_CULL=0 launches them one after the other)",
         "gpu_ms_per_step": {"mean": round(timed_ms["total"], 4), "median": round(timed_median["total"], 4), dom + "_median": round(timed_median[dom], 4),
                             "frames": timed_frames, "what": "first to last HIP event of a frame of the timed region (topo_get_timing_history, read after the region)"},
         "load_ms": round(load_ms, 4),

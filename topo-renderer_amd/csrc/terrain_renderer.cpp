@@ -446,8 +446,8 @@ int TerrainRenderer::render_frame(FrameCtx& c, hipStream_t stream, uint32_t n, c
     if (int rc = ensure_on(stream, &c.d_big, &c.cap_big, big_cap * sizeof(BigItem))) return rc;
     if (int rc = ensure_on(stream, &c.d_rare, &c.cap_rare, rare_cap * sizeof(RareItem))) return rc;
     if (!c.d_counters) {
-        if (int rc = ensure_on(stream, &c.d_counters, &c.cap_counters, kCounterWords * sizeof(uint32_t))) return rc;
-        TOPO_HIP_TRY(hipMemsetAsync(c.d_counters, 0, kCounterWords * sizeof(uint32_t), stream));
+        if (int rc = ensure_on(stream, &c.d_counters, &c.cap_counters, 2 * kCounterWords * sizeof(uint32_t))) return rc;      // two sets, alternating
+        TOPO_HIP_TRY(hipMemsetAsync(c.d_counters, 0, 2 * kCounterWords * sizeof(uint32_t), stream));
     }
     if (!c.h_status) TOPO_HIP_TRY(hipHostMalloc((void**)&c.h_status, kStatusRing * 16 * sizeof(uint32_t)));
     if (c.submitted - c.checked == kStatusRing) {      // nobody has waited for this context's frames for a whole ring: fold them now
@@ -484,7 +484,9 @@ int TerrainRenderer::render_frame(FrameCtx& c, hipStream_t stream, uint32_t n, c
     p.vis = (uint64_t*)c.d_vis;
     p.dirty = (uint8_t*)c.d_dirty;
     p.work = (WorkItem*)c.d_work;
-    p.counters = (uint32_t*)c.d_counters;
+    // this frame's counter set; the other one is zeroed by this frame's clear for the next frame of the context
+    p.counters = (uint32_t*)c.d_counters + (c.frames & 1u) * kCounterWords;
+    uint32_t* const counters_next = (uint32_t*)c.d_counters + ((c.frames & 1u) ^ 1u) * kCounterWords;
     p.big = (BigItem*)c.d_big;
     p.rare = (RareItem*)c.d_rare;
     p.far = (FarItem*)c.d_far;
@@ -543,9 +545,14 @@ int TerrainRenderer::render_frame(FrameCtx& c, hipStream_t stream, uint32_t n, c
     c.evr_frame[ring] = ++frame_seq_;
     ++c.frames;
     if (ev_need & (1u << 0)) TOPO_HIP_TRY(hipEventRecord(ev[0], stream));
-    launch_clear(p, stream);
+    // clear and cull side by side in one launch (timing slot "clear" then holds both, "cull" nothing); TOPO_FUSE_CLEAR_CULL=0 or
+    // an empty tile set: one after the other
+    static const bool fuse_off = getenv("TOPO_FUSE_CLEAR_CULL") && atoi(getenv("TOPO_FUSE_CLEAR_CULL")) == 0;
+    const bool fuse = !fuse_off && n_tiles != 0;
+    if (fuse) launch_clear_cull(p, counters_next, stream);
+    else launch_clear(p, counters_next, stream);
     if (ev_need & (1u << 1)) TOPO_HIP_TRY(hipEventRecord(ev[1], stream));
-    launch_cull(p, stream);
+    if (!fuse) launch_cull(p, stream);
     if (ev_need & (1u << 2)) TOPO_HIP_TRY(hipEventRecord(ev[2], stream));
     launch_raster(p, 0, stream);
     if (ev_need & (1u << 3)) TOPO_HIP_TRY(hipEventRecord(ev[3], stream));
@@ -599,7 +606,7 @@ int TerrainRenderer::render_frame(FrameCtx& c, hipStream_t stream, uint32_t n, c
     }
     if (ev_need & (1u << 8)) TOPO_HIP_TRY(hipEventRecord(ev[8], stream));
     // this frame's counters (queue fills, status bits), for whoever waits for the frame (check_frames, get_counters)
-    TOPO_HIP_TRY(hipMemcpyAsync(c.h_status + (c.submitted % kStatusRing) * 16, c.d_counters, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    TOPO_HIP_TRY(hipMemcpyAsync(c.h_status + (c.submitted % kStatusRing) * 16, p.counters, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     ++c.submitted;
     c.timed = true;
     TOPO_HIP_TRY(hipGetLastError());

@@ -50,7 +50,7 @@ struct FrameParams {
     WorkItem* work;
     uint32_t* counters;        // [0] near work count, [1] big count, [2] status bits, [3] rare count, [4] far candidates,
                                // [5] far survivors, [6] big start, [7] rare start (of the current phase), [8..10] first
-                               // bounds violation (check build); 16 words, all reset by k_clear at the start of a frame
+                               // bounds violation (check build); 16 words; two sets per frame context, alternating: a frame's set was zeroed by the clear of the frame before
     BigItem* big;
     RareItem* rare;
     FarItem* far;              // far candidates (k_cull -> k_occlusion)
@@ -119,7 +119,9 @@ void launch_normals_border(const TileDev* tiles, const EdgeJob* edges, uint32_t 
                            uint32_t h, hipStream_t s);      // the seam and corner passes of any number of jobs, one launch
 
 // frame phase (render)
-void launch_clear(const FrameParams& p, hipStream_t s);   // re-initialises the marked segments and the queue counters
+// `zero`: the counter set of the NEXT frame (the two sets of a frame context alternate), zeroed by the clear
+void launch_clear(const FrameParams& p, uint32_t* zero, hipStream_t s);        // re-initialises the marked segments
+void launch_clear_cull(const FrameParams& p, uint32_t* zero, hipStream_t s);   // the clear and the cull in one launch, side by side
 void launch_cull(const FrameParams& p, hipStream_t s);
 void launch_raster(const FrameParams& p, int phase, hipStream_t s);   // phase 0: near list, 1: far survivors
 void launch_occlusion(const FrameParams& p, hipStream_t s);
