@@ -760,8 +760,9 @@ __device__ __forceinline__ void cull_body(const FrameParams& P, uint32_t block) 
         const float* m = P.views[view].proj;
         double bxlo = 1e30, bxhi = -1e30, bylo = 1e30, byhi = -1e30, wmin = 1e30, zclip_at_wmin = 0.0;
         const double hs[2] = {hmin - 1.0, hmax + 2.0 + t.block_bounds[(size_t)blocks_per_tile * 16 + blk]};      // + the patch's sagitta (<= 1 m here)
+#pragma unroll 1      // (eight corners unrolled kept 124 registers live; the loop form needs half, and the clear running beside this kernel gets the waves)
         for (int k = 0; k < 8; ++k) {
-            const double R = (double)kR0 + hs[k >> 2];
+            const double R = (double)kR0 + (k < 4 ? hs[0] : hs[1]);
             const double px = R * bb[3 * (k & 3)], py = R * bb[3 * (k & 3) + 1], pz = R * bb[3 * (k & 3) + 2];
             const double cx = (double)m[0] * px + (double)m[4] * py + (double)m[8] * pz + (double)m[12];
             const double cy = (double)m[1] * px + (double)m[5] * py + (double)m[9] * pz + (double)m[13];
@@ -805,10 +806,14 @@ __global__ __launch_bounds__(256) void k_cull(FrameParams P) { cull_body(P, bloc
 // The clear and the cull of a frame in ONE launch: they share nothing (the clear rewrites visibility keys and zeroes the NEXT
 // frame's counters, the cull reads the load-time tables and appends through this frame's counters), one is bound by its
 // stores, the other by f64 arithmetic and gathers -- side by side they take what the clear takes alone (c4: 0.046 + 0.031 ->
-// 0.05 ms).  The cull's workgroups come first in the launch order, the clear's fill the chip behind them.
+// 0.05 ms).
 __global__ __launch_bounds__(256) void k_clear_cull(FrameParams P, uint32_t n_cull_blocks, uint32_t n_clear_blocks, uint32_t* __restrict__ zero) {
-    if (blockIdx.x < n_cull_blocks) cull_body(P, blockIdx.x);
-    else clear_body(P.vis, P.dirty, (size_t)P.n_views * P.W * P.H, P.counters, zero, blockIdx.x - n_cull_blocks, n_clear_blocks);
+    // the two kinds of workgroup interleaved evenly along the launch order (all of one kind first would run them one after the other:
+    // a launch's workgroups start in order)
+    const uint32_t total = n_cull_blocks + n_clear_blocks;
+    const uint32_t before = (uint32_t)((uint64_t)blockIdx.x * n_clear_blocks / total), upto = (uint32_t)((uint64_t)(blockIdx.x + 1u) * n_clear_blocks / total);
+    if (upto > before) clear_body(P.vis, P.dirty, (size_t)P.n_views * P.W * P.H, P.counters, zero, before, n_clear_blocks);
+    else cull_body(P, blockIdx.x - before);
 }
 
 // One wave per far candidate: the block is dropped iff EVERY pixel of its footprint already holds a depth below
