@@ -1420,7 +1420,16 @@ __global__ __launch_bounds__(256, TOPO_RESOLVE_WGS) void k_resolve(FrameParams P
     __shared__ float s_ndec[256];      // normal channel decode 2c/255 - 1
     __shared__ uint32_t s_lut[1024];   // 4096 one-byte bins of srgb_encode_lut
     __shared__ float s_lin[4][kRPW + 2][66];                 // per wave: linear depth of the strip + halo
-    __shared__ uint32_t s_rec[4][kTriRecordWords][kRecCap];  // per wave: the records, word-major (lanes with consecutive slots hit consecutive banks)
+#ifdef TOPO_EXP_REC_WORDMAJOR      // experiment build: the round-2 layout (word-major: 34 + 17 LDS instructions per record written / read)
+    __shared__ uint32_t s_rec[4][kTriRecordWords][kRecCap];
+#define TOPO_REC_AT(wv, slot, word) s_rec[wv][word][slot]
+#else
+    // per wave: the records, record-major at a stride of 36 words (16-byte aligned): a record is written and read as nine 16-byte
+    // LDS operations instead of 34 / 17 four- and eight-byte ones
+    constexpr int kRecStride = (kTriRecordWords + 3) & ~3;
+    __shared__ __attribute__((aligned(16))) uint32_t s_rec[4][kRecCap][kRecStride];
+#define TOPO_REC_AT(wv, slot, word) s_rec[wv][slot][word]
+#endif
     __shared__ uint32_t s_uid[4][kRecCap];                   // per wave: the distinct winner ids of a group of rows
     __shared__ uint8_t s_slot[4][kRPW][64];                  // per wave and pixel: the number of its entry among the strip's table entries (0xFF: none)
     const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1622,7 +1631,7 @@ __global__ __launch_bounds__(256, TOPO_RESOLVE_WGS) void k_resolve(FrameParams P
                         if (TOPO_CHK(P.counters, rank < P.n_tiles, 13u, id)) resolve_setup<true>(P.tiles[rank], P.tile_w, P.div_hm1, P.tile_h - 1, view, P.W, P.H, tri, fan, s_ndec, B.bx, y0, rec);
                         else rec = TriRecord{};
                         int k = 0;
-#define TOPO_X(f) s_rec[wave][k++][lane] = rec.f;
+#define TOPO_X(f) TOPO_REC_AT(wave, lane, k++) = rec.f;
                         TOPO_TRIREC_WORDS(TOPO_X)
 #undef TOPO_X
                     }
@@ -1657,7 +1666,7 @@ __global__ __launch_bounds__(256, TOPO_RESOLVE_WGS) void k_resolve(FrameParams P
                             const uint32_t sl = sel - gbase;
                             TriRecord rec;
                             int k = 0;
-#define TOPO_X(f) rec.f = s_rec[wave][k++][sl];
+#define TOPO_X(f) rec.f = TOPO_REC_AT(wave, sl, k++);
                             TOPO_TRIREC_WORDS(TOPO_X)
 #undef TOPO_X
                             const PixelAt at = {px, py, lane_d, (double)r, gx, pixel_gy(py, two_over_h)};
