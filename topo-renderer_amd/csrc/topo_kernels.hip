@@ -15,6 +15,7 @@
 #include "topo_kernels.h"
 
 #include <atomic>
+#include <type_traits>
 
 namespace topo {
 
@@ -1638,65 +1639,77 @@ __global__ __launch_bounds__(256, TOPO_RESOLVE_WGS) void k_resolve(FrameParams P
                     wave_lds_fence();
                 }
                 TOPO_PROF(5)  // winners: entries, records (gathers)
-#pragma unroll 1
-                for (int32_t r = r0; r < r1; ++r, rgba_p += O.rgba_pitch) {
-                    const int32_t py = y0 + r;
-                    // the pixel's entry number (rows shaded from the table) or its winner id
-                    const uint32_t sel = table ? (uint32_t)slot_tile[r][tx] : (in_x ? resolve_reload_id(P, B, px, py) : kNoTri);
-                    // the contour taps first: they depend on nothing, so their LDS trip overlaps the record's
-                    float ln[8];
-                    {
-                        int k = 0;
-#pragma unroll
-                        for (int i = -1; i <= 1; ++i)
-#pragma unroll
-                            for (int j = -1; j <= 1; ++j) {
-                                if (i == 0 && j == 0) continue;
-                                ln[k++] = lin_tile[r + 1 + j][tx + 1 + i];
-                            }
-                    }
-                    const float lin_c = lin_tile[r + 1][tx + 1];
-                    // render target texel (Rgba8UnormSrgb): the cleared value or the shaded winner
-                    uint32_t c8 = P.sky_c8;
-                    if (sel != (table ? 0xFFu : kNoTri)) {
-                        float lin[4] = {0.0f, 0.71f, 0.885f, 1.0f};
-                        f3 wpos = {0.0f, 0.0f, 0.0f}, wnrm;
-                        bool ok;
-                        if (table) {
-                            const uint32_t sl = sel - gbase;
-                            TriRecord rec;
+                // One row of the group.  The two ways a row gets its varyings -- from the wave's record table, or in one step per pixel
+                // with memory loads of its own (rows with more winners than the table holds: 0.5 % at c4) -- are two INSTANCES of
+                // this body, each in a loop of its own: in one loop the compiler had to assume the memory loads of the second form
+                // pending in the first as well, and every table row began by waiting for the previous row's output store to land
+                // (s_waitcnt vmcnt(0)).
+                auto shade_row = [&](auto table_tag, int32_t r) __attribute__((always_inline)) {
+                    constexpr bool kTable = decltype(table_tag)::value;
+                        const int32_t py = y0 + r;
+                        // the pixel's entry number (rows shaded from the table) or its winner id
+                        const uint32_t sel = kTable ? (uint32_t)slot_tile[r][tx] : (in_x ? resolve_reload_id(P, B, px, py) : kNoTri);
+                        // the contour taps first: they depend on nothing, so their LDS trip overlaps the record's
+                        float ln[8];
+                        {
                             int k = 0;
-#define TOPO_X(f) rec.f = TOPO_REC_AT(wave, sl, k++);
-                            TOPO_TRIREC_WORDS(TOPO_X)
-#undef TOPO_X
-                            const PixelAt at = {px, py, lane_d, (double)r, gx, pixel_gy(py, two_over_h)};
-                            ok = resolve_pixel(rec, at, wpos.x, wpos.y, wnrm);
-#ifdef TOPO_RESOLVE_STATS
-                            { const uint32_t n3 = (uint32_t)__popcll(__ballot(rec.kind == 3u)); if (n3 && lane == (uint32_t)__builtin_ctzll(__ballot(true))) atomicAdd(&P.counters[11], n3); }
-#endif
-                        } else {
-                            const uint32_t draw = sel >> 1, fan = sel & 1u;
-                            const uint32_t rank = fastdiv(draw, P.div_tris), tri = draw - rank * P.tris_per_tile;
-                            ok = TOPO_CHK(P.counters, rank < P.n_tiles, 13u, sel) &&
-                                 resolve_varyings<true>(P.tiles[rank], P.tile_w, P.div_hm1, P.tile_h - 1, view, P.W, P.H, tri, fan, s_ndec, px, py, wpos, wnrm);
+    #pragma unroll
+                            for (int i = -1; i <= 1; ++i)
+    #pragma unroll
+                                for (int j = -1; j <= 1; ++j) {
+                                    if (i == 0 && j == 0) continue;
+                                    ln[k++] = lin_tile[r + 1 + j][tx + 1 + i];
+                                }
                         }
-                        if (ok) shade_fragment(view_mode, sun, cam_x, cam_y, (float)px + 0.5f, (float)py + 0.5f, wpos, wnrm, lin);
-                        c8 = (kSrgb ? srgb_encode_lut3(s_thresh, lut, lin[0], lin[1], lin[2]) : to_unorm8(lin[0]) | (to_unorm8(lin[1]) << 8) | (to_unorm8(lin[2]) << 16)) |
-                             (to_unorm8(lin[3]) << 24);
-                    }
-                    // The post pass.  Its contour factor a is 0 iff RN(contour / centre) <= 0.05f; contour <= 0.0499f * centre
-                    // (centre is a linear depth: 50 .. 5e5) puts the quotient below 0.04991: such a pixel returns its texel
-                    // unchanged, and a row of them skips the divisions.  (A NaN fails the comparison and takes the long route.)
-                    float contour = 8.0f * lin_c;
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) contour -= ln[k];
-                    uint32_t out = c8;
-                    const bool long_post = !P.post_off && __ballot(!(contour <= 0.0499f * lin_c)) != 0ull;      // (post_off: the render-target texel itself)
-#ifdef TOPO_RESOLVE_STATS
-                    if (lane == 0) { atomicAdd(&P.counters[table ? 8 : 9], 1u); if (long_post) atomicAdd(&P.counters[10], 1u); }
-#endif
-                    if (long_post) out = post_pixel_t<true>(s_thresh, s_decode, c8, lin_c, ln, lut, kSrgb);
-                    if (in_x) *reinterpret_cast<uint32_t*>(rgba_p) = surface_order<kBgra>(out);
+                        const float lin_c = lin_tile[r + 1][tx + 1];
+                        // render target texel (Rgba8UnormSrgb): the cleared value or the shaded winner
+                        uint32_t c8 = P.sky_c8;
+                        if (sel != (kTable ? 0xFFu : kNoTri)) {
+                            float lin[4] = {0.0f, 0.71f, 0.885f, 1.0f};
+                            f3 wpos = {0.0f, 0.0f, 0.0f}, wnrm;
+                            bool ok;
+                            if (kTable) {
+                                const uint32_t sl = sel - gbase;
+                                TriRecord rec;
+                                int k = 0;
+    #define TOPO_X(f) rec.f = TOPO_REC_AT(wave, sl, k++);
+                                TOPO_TRIREC_WORDS(TOPO_X)
+    #undef TOPO_X
+                                const PixelAt at = {px, py, lane_d, (double)r, gx, pixel_gy(py, two_over_h)};
+                                ok = resolve_pixel(rec, at, wpos.x, wpos.y, wnrm);
+    #ifdef TOPO_RESOLVE_STATS
+                                { const uint32_t n3 = (uint32_t)__popcll(__ballot(rec.kind == 3u)); if (n3 && lane == (uint32_t)__builtin_ctzll(__ballot(true))) atomicAdd(&P.counters[11], n3); }
+    #endif
+                            } else {
+                                const uint32_t draw = sel >> 1, fan = sel & 1u;
+                                const uint32_t rank = fastdiv(draw, P.div_tris), tri = draw - rank * P.tris_per_tile;
+                                ok = TOPO_CHK(P.counters, rank < P.n_tiles, 13u, sel) &&
+                                     resolve_varyings<true>(P.tiles[rank], P.tile_w, P.div_hm1, P.tile_h - 1, view, P.W, P.H, tri, fan, s_ndec, px, py, wpos, wnrm);
+                            }
+                            if (ok) shade_fragment(view_mode, sun, cam_x, cam_y, (float)px + 0.5f, (float)py + 0.5f, wpos, wnrm, lin);
+                            c8 = (kSrgb ? srgb_encode_lut3(s_thresh, lut, lin[0], lin[1], lin[2]) : to_unorm8(lin[0]) | (to_unorm8(lin[1]) << 8) | (to_unorm8(lin[2]) << 16)) |
+                                 (to_unorm8(lin[3]) << 24);
+                        }
+                        // The post pass.  Its contour factor a is 0 iff RN(contour / centre) <= 0.05f; contour <= 0.0499f * centre
+                        // (centre is a linear depth: 50 .. 5e5) puts the quotient below 0.04991: such a pixel returns its texel
+                        // unchanged, and a row of them skips the divisions.  (A NaN fails the comparison and takes the long route.)
+                        float contour = 8.0f * lin_c;
+    #pragma unroll
+                        for (int k = 0; k < 8; ++k) contour -= ln[k];
+                        uint32_t out = c8;
+                        const bool long_post = !P.post_off && __ballot(!(contour <= 0.0499f * lin_c)) != 0ull;      // (post_off: the render-target texel itself)
+    #ifdef TOPO_RESOLVE_STATS
+                        if (lane == 0) { atomicAdd(&P.counters[kTable ? 8 : 9], 1u); if (long_post) atomicAdd(&P.counters[10], 1u); }
+    #endif
+                        if (long_post) out = post_pixel_t<true>(s_thresh, s_decode, c8, lin_c, ln, lut, kSrgb);
+                        if (in_x) *reinterpret_cast<uint32_t*>(rgba_p) = surface_order<kBgra>(out);
+                };
+                if (table) {
+#pragma unroll 1
+                    for (int32_t r = r0; r < r1; ++r, rgba_p += O.rgba_pitch) shade_row(std::true_type{}, r);
+                } else {
+#pragma unroll 1
+                    for (int32_t r = r0; r < r1; ++r, rgba_p += O.rgba_pitch) shade_row(std::false_type{}, r);
                 }
                 TOPO_PROF(6)  // pixels
                 gbase += table ? cnt : 0u;
