@@ -1079,10 +1079,24 @@ __global__ __launch_bounds__(256, TOPO_RASTER_WAVES) void k_raster(FrameParams P
     uint32_t ntri = 0;           // triangles waiting in tl (wave-uniform)
     const uint32_t wave_global = blockIdx.x * 4 + wave, wave_count = gridDim.x * 4;
     for (uint32_t item = wave_global; item < count; item += wave_count) {
-        const WorkItem wi = work[item];
+        // The work item, the tile's descriptor and the view matrix are wave-uniform and written by EARLIER kernels: read through
+        // the constant address space they come over the scalar data path (s_load), in two round trips -- item, then descriptor
+        // and matrix together -- that wait on lgkmcnt.  As vector loads they were four dependent trips behind s_waitcnt vmcnt(0),
+        // each of which also waits for every visibility atomic the wave still has in flight from the strip before.
+        typedef const __attribute__((address_space(4))) uint32_t* cu32;
+        typedef const __attribute__((address_space(4))) float* cf32;
+        const cu32 wi_c = (cu32)(const void*)(work + item);
+        const WorkItem wi = {wi_c[0], wi_c[1]};
         const uint32_t view_idx = wi.view_rank >> 16, rank = wi.view_rank & 0xFFFFu;
-        const TileDev& t = P.tiles[rank];
-        const ViewDev& view = P.views[view_idx];
+        TileDev t;      // the fields this kernel reads (the rest stay unset)
+        {
+            const auto tc = (const __attribute__((address_space(4))) TileDev*)(const void*)(P.tiles + rank);
+            t.heights = tc->heights;
+            t.raster_x = tc->raster_x; t.raster_y = tc->raster_y;
+            t.model_x = tc->model_x; t.model_y = tc->model_y;
+            t.scale_x = tc->scale_x; t.scale_y = tc->scale_y;
+        }
+        const cf32 view_proj = (cf32)(const void*)P.views[view_idx].proj;
         const uint32_t blk_id = wi.block & 0xFFFFFFu, strip_first = (wi.block >> 24) & 15u, strip_rows = wi.block >> 28;
         const uint32_t bx = blk_id % P.bx_count, by = blk_id / P.bx_count;
         const uint32_t x0 = bx * kBCX, y0 = by * kBCY + strip_first;   // strip_rows == 0: the whole block
@@ -1096,7 +1110,7 @@ __global__ __launch_bounds__(256, TOPO_RASTER_WAVES) void k_raster(FrameParams P
         // s_waitcnt vmcnt(0) that also drains the height prefetch
         float proj[16];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) proj[q] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(view.proj[q])));
+        for (int q = 0; q < 16; ++q) proj[q] = view_proj[q];
         if (lane == 0) fl.count = 0;
         float slo, clo, lat_s = 0.0f, lat_c = 0.0f;
         sincos_f(vertex_lon(t, vcol ? vx : x0), slo, clo);
