@@ -455,7 +455,10 @@ __global__ __launch_bounds__(64 * kWaves) void k_normals_rolling(const TileDev* 
     const TileDev& t = tiles[first + bz];
     const auto heights = TOPO_GLOBAL_F32(t.heights);
     const auto normals = TOPO_GLOBAL_U32_RW(t.normals);
-    const auto trig_lat = TOPO_GLOBAL_F32(t.trig_lat);
+    // (the table was written by an earlier launch and a row's entry is wave-uniform: read through the constant address space it
+    // comes over the scalar data path.  As a vector load it was the youngest memory operation of its row, and waiting for it --
+    // s_waitcnt vmcnt(0) -- waited for every row in flight and for the previous row's store as well.)
+    const auto trig_lat = (const __attribute__((address_space(4))) float*)(const void*)t.trig_lat;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int x0 = (int)bx_ * kCols, c0 = x0 + 4 * lane;
     const int y0 = (int)by_ * kChunkRows + wave * kRollRows;
@@ -489,12 +492,15 @@ __global__ __launch_bounds__(64 * kWaves) void k_normals_rolling(const TileDev* 
 #pragma unroll
                 for (int k = 0; k < kBatch; ++k) { nx[k] = load4(y + kBatch + 1 + k); ne[k] = load_edge(y + kBatch + 1 + k); }
             }
+            float cos_lat[kBatch];      // (all of a round's scalar loads up front)
+#pragma unroll
+            for (int k = 0; k < kBatch; ++k) cos_lat[k] = trig_lat[2 * (y + k < H ? y + k : H - 1) + 1];
 #pragma unroll
             for (int k = 0; k < kBatch; ++k) {
                 const int gy = y + k;
                 if (gy >= y1) break;      // (wave-uniform)
                 const f32x4_t below = cur[k];
-                const float ys = ys0 * unif_first(trig_lat[2 * gy + 1]);
+                const float ys = ys0 * cos_lat[k];
                 const float left_edge = unif2(mid_edge, 0), right_edge = unif2(mid_edge, 63);
                 const float hl = wave_from_left(mid.w, left_edge), hr = wave_from_right(mid.x, right_edge);
                 if (kTables) {
