@@ -14,6 +14,8 @@ for w in c1 c2 c3; do
 done
 timeout -k 10 900 python3 bench.py --workload c4 --check --also-pipelined > $O/bench_c4.json 2> $O/bench_c4.err; echo "c4 done"
 timeout -k 10 300 python3 bench.py --workload c4 --pipeline 2 --steps 20 --no-cpu-baseline --no-pmc > $O/bench_c4_pipelined.json 2> $O/bench_c4_pipelined.err; echo "c4 pipelined done"
+timeout -k 10 600 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "default done"
+TOPO_LOAD_FUSED=0 timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-pmc --steps 5 > $O/bench_c4_separate_load.json 2> $O/bench_c4_separate_load.err; echo "separate-load done"
 timeout -k 10 400 python3 bench.py --workload c5 --no-cpu-baseline --no-pmc --steps 2 --warmup 1 > $O/bench_c5.json 2> $O/bench_c5.err; echo "c5 done"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o c4 -- python3 $R/bench.py --workload c4 --no-cpu-baseline --no-pmc > $O/stats.log 2>&1; echo "stats done"
