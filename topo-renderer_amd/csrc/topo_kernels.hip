@@ -1194,9 +1194,15 @@ __global__ __launch_bounds__(256, TOPO_RASTER_WAVES) void k_raster(FrameParams P
 
 // One lane per RareItem: the generic exact path (near clipping, int64 setup).  Boxes up to 4x4 px are
 // rasterised in-lane, larger ones go to the big queue (or, if that is full, are rasterised here as well).
+// A triangle with at least kCoopRegions regions has its BigItems written by the WHOLE wave, 64 regions at a time: a lane's own loop
+// over the regions of a triangle that covers a good part of the target (the near field's largest, cut by the near plane: a thousand
+// regions and more) was this kernel's duration -- ~20 instructions per region on ONE lane, while the other 15 000 triangles had long
+// been done.
+constexpr uint32_t kCoopRegions = 24;
 __global__ __launch_bounds__(256) void k_raster_rare(FrameParams P) {
     uint32_t count = P.counters[3];
     if (count > P.rare_cap) count = P.rare_cap;
+    const uint32_t lane = threadIdx.x & 63;
     for (uint32_t item = P.counters[7] + blockIdx.x * blockDim.x + threadIdx.x; item < count; item += gridDim.x * blockDim.x) {
         const RareItem ri = P.rare[item];
         const uint32_t rank = fastdiv(ri.draw, P.div_tris), tri = ri.draw - rank * P.tris_per_tile;
@@ -1204,12 +1210,56 @@ __global__ __launch_bounds__(256) void k_raster_rare(FrameParams P) {
         const Vis vis = view_vis(P, ri.view);
         for (uint32_t fan = 0; fan < 2; ++fan) {
             ResolvedTri r;
-            if (!resolve_triangle(P.tiles[rank], P.tile_w, P.div_hm1, P.tile_h - 1, P.views[ri.view], P.W, P.H, tri, fan, r)) continue;
+            const bool has = resolve_triangle(P.tiles[rank], P.tile_w, P.div_hm1, P.tile_h - 1, P.views[ri.view], P.W, P.H, tri, fan, r);
             const TriSetup& ts = r.ts;
             const uint32_t id = (ri.draw << 1) | fan;
-            const int32_t nx = ts.px1 - ts.px0 + 1, ny = ts.py1 - ts.py0 + 1;
-            if ((nx <= 4 && ny <= 4) || !enqueue_big(P, ri.view, id, r.s[0], r.s[1], r.s[2], ts.px0, ts.px1, ts.py0, ts.py1))
-                raster_box(ts, vis, P.W, id, ts.px0, ts.px1, ts.py0, ts.py1);
+            const int32_t nx = has ? ts.px1 - ts.px0 + 1 : 0, ny = has ? ts.py1 - ts.py0 + 1 : 0;
+            const bool small = nx <= 4 && ny <= 4;
+            const int32_t rx0 = has ? ts.px0 >> 6 : 0, rx1 = has ? ts.px1 >> 6 : 0, ry0 = has ? ts.py0 >> 6 : 0, ry1 = has ? ts.py1 >> 6 : 0;
+            const uint32_t rw = (uint32_t)(rx1 - rx0 + 1), n_regions = rw * (uint32_t)(ry1 - ry0 + 1);
+            const bool coop = has && !small && n_regions >= kCoopRegions && rw <= 256u;
+            bool in_lane = has && small;      // rasterised by this lane itself: boxes up to 4 x 4 px, and whatever the queue has no room for
+            if (has && !small && !coop) in_lane = !enqueue_big(P, ri.view, id, r.s[0], r.s[1], r.s[2], ts.px0, ts.px1, ts.py0, ts.py1);
+            // ---- the wave's large jobs, one after the other, every lane that is still in this loop taking part
+            uint64_t jobs = __ballot(coop);
+            if (jobs) {
+                const uint64_t act = __ballot(true);
+                const uint32_t n_act = (uint32_t)__popcll(act), mine = (uint32_t)__popcll(act & ((1ull << lane) - 1ull));
+                while (jobs) {
+                    const int L = __builtin_ctzll(jobs);
+                    jobs &= jobs - 1ull;
+                    auto from = [&](int32_t v) { return __builtin_amdgcn_readlane(v, L); };
+                    BigItem it;
+                    it.view = (uint32_t)from((int32_t)ri.view);
+                    it.id = (uint32_t)from((int32_t)id);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        it.X[k] = from(r.s[k].X);
+                        it.Y[k] = from(r.s[k].Y);
+                        it.z[k] = __int_as_float(from(__float_as_int(r.s[k].z)));
+                    }
+                    const int32_t jx0 = from(rx0), jy0 = from(ry0);
+                    const uint32_t jw = (uint32_t)from((int32_t)rw), n = (uint32_t)from((int32_t)n_regions);
+                    uint32_t base = 0;
+                    if ((int)lane == L) base = atomicAdd(&P.counters[1], n);
+                    base = (uint32_t)from((int32_t)base);
+                    if (base >= P.big_cap || n > P.big_cap - base) {      // no room: neutralise the part of the reservation inside the queue; the owner rasterises
+                        if ((int)lane == L) { atomicOr(&P.counters[2], kStatusBigOverflow); in_lane = true; }
+                        it.id = kNoTri;
+                        it.region = 0;
+                        for (uint32_t k = mine; k < n && base + k < P.big_cap; k += n_act) P.big[base + k] = it;
+                        continue;
+                    }
+                    const uint32_t magic = (1u << 24) / jw + 1u;      // k / jw = k * magic >> 24, exact while k * jw < 2^24 (jw <= 256, k < 2^16)
+                    for (uint32_t k = mine; k < n; k += n_act) {
+                        const uint32_t q = n < 65536u ? (uint32_t)(((uint64_t)k * magic) >> 24) : k / jw;
+                        const int32_t ry = jy0 + (int32_t)q, rx = jx0 + (int32_t)(k - q * jw);
+                        it.region = ((uint32_t)ry << 16) | (uint32_t)rx;
+                        if (TOPO_CHK(P.counters, base + k < P.big_cap && rx >= 0 && ry >= 0 && rx * 64 < P.W && ry * 64 < P.H, 7u, base + k)) P.big[base + k] = it;
+                    }
+                }
+            }
+            if (in_lane) raster_box(ts, vis, P.W, id, ts.px0, ts.px1, ts.py0, ts.py1);
         }
     }
 }
