@@ -395,6 +395,23 @@ def test_queue_overflow_paths(topo, orc):
     g.debug_set_queue_caps(0, 0)
     assert_same_frame(g.render(), ref, "defaults restored")
     assert g.counters()["status"] == 0
+    # a larger target, where triangles span 24 regions and more: their region items are written by the whole wave (k_raster_rare),
+    # and a full queue sends such a triangle back to its lane -- all of it, or the part of a reservation that ran over the end
+    W2, H2 = 640, 480
+    g2, o2 = both(topo, orc, W2, H2)
+    sc.load(g2)
+    sc.load(o2)
+    u2, pu2 = sc.uniforms(W2, H2, 10, 35, 110, 0), topo.post_uniforms(W2, H2)
+    g2.update(W2, H2, u2, pu2)
+    o2.update(W2, H2, u2, pu2)
+    ref2 = o2.render()
+    assert_same_frame(g2.render(), ref2, "wave-written region items")
+    n_items = g2.counters()["big_items"]
+    assert n_items > 50, n_items
+    for cap in (16, 40, n_items // 2, n_items - 3):
+        g2.debug_set_queue_caps(cap, 0)
+        assert_same_frame(g2.render(), ref2, f"big queue of {cap} with wave-written items")
+        assert g2.counters()["status"] & 1
 
 
 def test_overflow_status_is_per_frame_on_the_async_paths(topo, orc):
