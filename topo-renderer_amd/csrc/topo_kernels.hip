@@ -1642,9 +1642,12 @@ __global__ __launch_bounds__(256, TOPO_RESOLVE_WGS) void k_resolve(FrameParams P
             // what fs_main reads of the view, once per strip and wave-uniform: left to the compiler these are re-loaded in every
             // row (it cannot prove the output stores do not alias them) behind an s_waitcnt vmcnt(0) that also waits for the
             // previous row's stores to land
-            const f3 sun = {unif(view.sun[0]), unif(view.sun[1]), unif(view.sun[2])};
-            const float cam_x = unif(view.cam_x), cam_y = unif(view.cam_y);
-            const int32_t view_mode = uni(view.view_mode);
+            // (over the scalar data path -- constant address space --: as vector loads they were waited for with s_waitcnt vmcnt(0)
+            // right behind the request for the next strip's keys, i.e. every strip began by sitting out that request's trip to HBM)
+            const auto view_c = (const __attribute__((address_space(4))) ViewDev*)(const void*)(P.views + B.view);
+            const f3 sun = {view_c->sun[0], view_c->sun[1], view_c->sun[2]};
+            const float cam_x = view_c->cam_x, cam_y = view_c->cam_y;
+            const int32_t view_mode = view_c->view_mode;
 #ifdef TOPO_RESOLVE_STATS      // experiment build: how well do winners share?  counters[12] entries, [13] waves with terrain, [14] groups, [15] terrain pixels
             {
                 uint32_t npx = 0;
