@@ -153,9 +153,15 @@ def main():
         dist.broadcast(uid, 0)
         dist.broadcast(ok, 0)
         if ok.item() > 0:
-            comm = T.Comm(rank, world, uid.cpu().numpy(), device=local_rank)
-        else:
+            try:
+                comm = T.Comm(rank, world, uid.cpu().numpy(), device=local_rank)
+            except T.TopoError as e:
+                ok.zero_()
+                comm_note = f"topo_comm_init failed on rank {rank}: {e}"
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if ok.item() == 0:
             use_capi_comm = False      # (every rank falls back together)
+            comm = None
     # one output set per frame in flight
     r.set_pipeline_depth(depth_frames)
     outs = [(torch.empty((N_SECTORS, PH, SW, 4), dtype=torch.uint8, device="cuda"),
@@ -182,6 +188,40 @@ def main():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+
+    # ---- N > 1: the C-ABI exchange has only ever run with a world of one (one-GPU boxes).  Its first frame is therefore a trial:
+    # every rank renders one panorama through it; if any rank gets an error, or the ranks do not end up with byte-identical
+    # strips, ALL ranks fall back together to the torch.distributed all-gather and the line says so (`exchange_note`).
+    if use_capi_comm:
+        ok = torch.ones(1, device="cuda")
+        try:
+            step()
+            r.synchronize()
+            torch.cuda.synchronize()
+        except T.TopoError as e:
+            ok.zero_()
+            comm_note = f"topo_render_panorama failed on rank {rank}: {e}"
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if ok.item() > 0:
+            # (a cheap fingerprint of the whole strip: 64-bit sums of its words, position-weighted)
+            w = strip.view(torch.int32).to(torch.int64).flatten()
+            fp = torch.stack([w.sum(), (w * (torch.arange(w.numel(), device="cuda") % 8191 + 1)).sum()])
+            lo, hi = fp.clone(), fp.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            if not torch.equal(lo, hi):
+                ok.zero_()
+                comm_note = "the ranks' strips differ after topo_render_panorama"
+        if ok.item() == 0:
+            use_capi_comm = False
+            if comm_note is None:
+                comm_note = "topo_render_panorama failed on another rank"
+            try:
+                r.synchronize()
+            except T.TopoError:
+                pass
+            torch.cuda.synchronize()
+            dist.barrier()
 
     # ---- per-kernel breakdown, from a few frames with every timing event on.  Each event between two kernels idles the GPU
     # for ~6 us, so the timed region below keeps only the events of the dominant kernel (and the frame total): its duration
