@@ -1561,8 +1561,14 @@ __global__ __launch_bounds__(256, TOPO_RESOLVE_WGS) void k_resolve(FrameParams P
         ResolveKeys K;
         uint32_t j_cur = 0;
         bool have = mm != 0ull;
+#ifdef TOPO_EXP_NO_PREFETCH      // experiment build: every strip's keys requested when the strip starts, none ahead (106 VGPRs instead of 125)
+        if (have) j_cur = pop_bit(mm);
+        while (have) {
+            resolve_load_keys(P, block_of(j_cur), lane, wave, K);
+#else
         if (have) { j_cur = pop_bit(mm); resolve_load_keys(P, block_of(j_cur), lane, wave, K); }
         while (have) {
+#endif
 #ifdef TOPO_RESOLVE_EARLY_PREFETCH      // experiment build: the next strip's keys requested at the top of the iteration, into registers of their own
             ResolveKeys Kn;
             const bool more = mm != 0ull;
@@ -1624,7 +1630,16 @@ __global__ __launch_bounds__(256, TOPO_RESOLVE_WGS) void k_resolve(FrameParams P
             // ---- this strip's keys are consumed: request the next strip's
             const bool more = mm != 0ull;
             uint32_t j_next = 0;
+            // (The wait counter is in order: the record pass below waits for its own loads -- cache hits -- behind this request's trip
+            // to HBM, so what the request hides of that trip at the next strip's start it costs here: TOPO_EXP_NO_PREFETCH, no request
+            // ahead at all, takes the same 0.371 ms.  Requesting BEHIND the record pass would hide the trip under the rows; every
+            // form of it tried -- the request inside the group loop, the first record pass peeled in front of the loop, its loads and
+            // its arithmetic as two calls with the request between them -- spilled 12 to 35 registers of this kernel's 125 and lost.)
+#ifdef TOPO_EXP_NO_PREFETCH
+            if (more) j_next = pop_bit(mm);
+#else
             if (more) { j_next = pop_bit(mm); resolve_load_keys(P, block_of(j_next), lane, wave, K); }
+#endif
 #endif
             for (uint32_t f = 0; f < fills_per_iter && mc; ++f) resolve_fill_sky<kBgra>(P, O, block_of(pop_bit(mc)), lane, wave);
             TOPO_PROF(1)  // issue of the next keys + sky fills
