@@ -1364,11 +1364,11 @@ constexpr int kResolveRows = 4 * kRPW;
 static_assert(kResolveRows == (int)kResolveBlockH && kResolveBlockW == 64u, "the host sizes k_resolve's block grid from these");
 static_assert(kRPW == 4 || kRPW == 8, "RowN below names the rows of a wave");
 #ifndef TOPO_RESOLVE_RECS
-#define TOPO_RESOLVE_RECS 32
+#define TOPO_RESOLVE_RECS 20      // (20 records + 5 workgroups per CU beat 32 + 4: the table's 4.6 KB are what the fifth workgroup's LDS needs)
 #endif
 constexpr uint32_t kRecCap = TOPO_RESOLVE_RECS;    // triangle records per wave
 #ifndef TOPO_RESOLVE_WGS
-#define TOPO_RESOLVE_WGS 4
+#define TOPO_RESOLVE_WGS 5
 #endif
 // One value per row of a wave.  Named members, not an array: an array indexed by a loop variable goes to scratch memory.
 template <typename T>
@@ -1561,7 +1561,7 @@ __global__ __launch_bounds__(256, TOPO_RESOLVE_WGS) void k_resolve(FrameParams P
         ResolveKeys K;
         uint32_t j_cur = 0;
         bool have = mm != 0ull;
-#ifdef TOPO_EXP_NO_PREFETCH      // experiment build: every strip's keys requested when the strip starts, none ahead (106 VGPRs instead of 125)
+#ifndef TOPO_EXP_KEY_PREFETCH      // every strip's keys are requested when the strip starts, none ahead (TOPO_EXP_KEY_PREFETCH: the round-2 form, see below)
         if (have) j_cur = pop_bit(mm);
         while (have) {
             resolve_load_keys(P, block_of(j_cur), lane, wave, K);
@@ -1630,12 +1630,14 @@ __global__ __launch_bounds__(256, TOPO_RESOLVE_WGS) void k_resolve(FrameParams P
             // ---- this strip's keys are consumed: request the next strip's
             const bool more = mm != 0ull;
             uint32_t j_next = 0;
-            // (The wait counter is in order: the record pass below waits for its own loads -- cache hits -- behind this request's trip
-            // to HBM, so what the request hides of that trip at the next strip's start it costs here: TOPO_EXP_NO_PREFETCH, no request
-            // ahead at all, takes the same 0.371 ms.  Requesting BEHIND the record pass would hide the trip under the rows; every
-            // form of it tried -- the request inside the group loop, the first record pass peeled in front of the loop, its loads and
-            // its arithmetic as two calls with the request between them -- spilled 12 to 35 registers of this kernel's 125 and lost.)
-#ifdef TOPO_EXP_NO_PREFETCH
+            // (Rounds 2 and 3 requested the NEXT strip's keys here, to travel under the record pass and the rows.  But the wait counter
+            // is in order: the record pass below waits for its own loads -- cache hits -- behind that request's trip to HBM, so what
+            // the request hid of the trip at the next strip's start it cost here: with no request ahead at all the kernel took the
+            // same 0.371 ms -- with 106 registers instead of 125, which is what lets a fifth workgroup onto the CU (0.362 ms).
+            // Requesting BEHIND the record pass would hide the trip under the rows; every form of it tried -- the request inside the
+            // group loop, the first record pass peeled in front of the loop, its loads and its arithmetic as two calls with the request
+            // between them -- spilled 12 to 35 registers and lost.)
+#ifndef TOPO_EXP_KEY_PREFETCH
             if (more) j_next = pop_bit(mm);
 #else
             if (more) { j_next = pop_bit(mm); resolve_load_keys(P, block_of(j_next), lane, wave, K); }
