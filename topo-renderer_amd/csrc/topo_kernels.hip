@@ -1565,6 +1565,8 @@ __global__ __launch_bounds__(256, TOPO_RESOLVE_WGS) void k_resolve(FrameParams P
         if (have) j_cur = pop_bit(mm);
         while (have) {
             resolve_load_keys(P, block_of(j_cur), lane, wave, K);
+            // (this strip's share of the untouched strips -- pure stores -- goes out under the keys' trip to memory)
+            for (uint32_t f = 0; f < fills_per_iter && mc; ++f) resolve_fill_sky<kBgra>(P, O, block_of(pop_bit(mc)), lane, wave);
 #else
         if (have) { j_cur = pop_bit(mm); resolve_load_keys(P, block_of(j_cur), lane, wave, K); }
         while (have) {
@@ -1643,7 +1645,9 @@ __global__ __launch_bounds__(256, TOPO_RESOLVE_WGS) void k_resolve(FrameParams P
             if (more) { j_next = pop_bit(mm); resolve_load_keys(P, block_of(j_next), lane, wave, K); }
 #endif
 #endif
+#ifdef TOPO_EXP_KEY_PREFETCH
             for (uint32_t f = 0; f < fills_per_iter && mc; ++f) resolve_fill_sky<kBgra>(P, O, block_of(pop_bit(mc)), lane, wave);
+#endif
             TOPO_PROF(1)  // issue of the next keys + sky fills
             if (!any_terrain) {                // marked, but every key still cleared (a mark covers 64 keys): the cleared texel and depth 1
                 resolve_fill_sky<kBgra>(P, O, B, lane, wave);
