@@ -38,4 +38,11 @@ for n_ranks in (1, 2, 4, 8):
             r.render_views_device(vs, SW, PH, rgba.data_ptr() + rank * per * VS, VS, SW * 4, depth.data_ptr() + rank * per * VS, VS, SW * 4)
         r.synchronize(); torch.cuda.synchronize()
         worst = max(worst, (time.perf_counter() - t0) / K * 1e3)
-    print(f"N = {n_ranks}: {per} sectors per rank, slowest rank's share {worst:.4f} ms", flush=True)
+    r.set_timing_slots(None)      # (every timing event on: the kernels' own durations, ~6 us of idle GPU per event on top of `worst`)
+    for _ in range(3):
+        r.render_views_device(views[:per], SW, PH, rgba.data_ptr(), VS, SW * 4, depth.data_ptr(), VS, SW * 4)
+        r.synchronize()
+    tm = r.timings()
+    r.set_timing_slots(())
+    print(f"N = {n_ranks}: {per} sectors per rank, slowest rank's share {worst:.4f} ms; kernels of rank 0's share: "
+          + ", ".join(f"{k} {tm[k]:.3f}" for k in ("clear", "cull", "raster", "raster_big", "occlusion", "resolve", "total")), flush=True)
