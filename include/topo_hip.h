@@ -278,7 +278,9 @@ int topo_get_timing_history(topo_ctx* ctx, uint32_t n_frames, float* out_ms, uin
 /* Which of the slots [0]..[5] to measure (bit i = slot i; default all).  Every timing event between two kernels leaves the
  * GPU idle for ~6 us while the marker completes -- 4 % of a c4 frame, a third of a c1 frame with all nine events -- so a
  * caller that only wants one kernel's duration (bench.py: the dominant one) or none selects just that; unselected slots
- * read 0, the total [6] is always measured. */
+ * read 0.  The total [6] (an event in front of the frame's first kernel and one behind its last) is measured unless
+ * TOPO_TIMING_NO_TOTAL is or'ed into the mask (then it reads 0 too; slot_mask = TOPO_TIMING_NO_TOTAL: no events at all). */
+#define TOPO_TIMING_NO_TOTAL 0x80u
 int topo_set_timing_slots(topo_ctx* ctx, uint32_t slot_mask);
 
 /* Counters of the last topo_render* call: [0] near blocks rastered, [1] big-triangle items, [2] that frame's status bits

@@ -20,6 +20,11 @@ extern "C" {
  * grow on demand", i.e. the default behaviour from a small starting size. */
 int topo_debug_set_queue_caps(topo_ctx* ctx, uint32_t big_cap, uint32_t rare_cap);
 
+/* Test accessor: 1 if the last submission launched its far phase (occlusion test + second raster pass), 0 if the host could
+ * prove that no block lies beyond the occlusion split (a lone tile around the viewpoint) and left the four launches out.
+ * TOPO_FAR_SKIP=0 in the environment always launches it. */
+int topo_debug_far_phase_launched(topo_ctx* ctx, int32_t* out);
+
 /* Test accessor: the tile's Rgba8Unorm normal texture, w*h*4 bytes, host pointer. */
 int topo_read_normals(topo_ctx* ctx, int32_t lat_deg, int32_t lon_deg, uint8_t* out);
 

@@ -832,6 +832,13 @@ def test_sixty_four_views_in_one_submission(topo, orc):
     for k in (0, 7, 8, 21, 38, 63):
         o.update(W, H, views[k], topo.post_uniforms(W, H))
         assert_same_frame((sh[k], dh[k]), o.render(), f"view {k} of 64")
+    # up to eight views travel as a kernel argument (k_put_views), more through the pinned staging ring: same frames either way
+    for lo in (0, 24, 56):
+        s8 = torch.zeros((8, H, W, 4), dtype=torch.uint8, device="cuda")
+        d8 = torch.zeros((8, H, W), dtype=torch.float32, device="cuda")
+        g.render_views_device(packed[lo:lo + 8], W, H, s8.data_ptr(), H * W * 4, W * 4, d8.data_ptr(), H * W * 4, W * 4)
+        g.synchronize()
+        assert np.array_equal(s8.cpu().numpy(), sh[lo:lo + 8]) and np.array_equal(d8.cpu().numpy().view(np.uint32), dh[lo:lo + 8].view(np.uint32)), lo
     with pytest.raises(topo.TopoError):
         g.render_views_device(views + views[:1], W, H, s.data_ptr(), H * W * 4, W * 4, d.data_ptr(), H * W * 4, W * 4)
 
@@ -882,7 +889,8 @@ def test_strip_edges_of_the_resolve_pass(topo, orc):
 
 
 def test_timing_slots_select_events(topo, orc):
-    """topo_set_timing_slots: unselected per-kernel slots read 0, the total is always measured, frames are unchanged."""
+    """topo_set_timing_slots: unselected per-kernel slots read 0, the total is measured unless TOPO_TIMING_NO_TOTAL is set, frames
+    are unchanged (and so are the counters, which k_resolve stores into the pinned status ring itself)."""
     sc = Scene(64, 1, 1, eye_dh=60)
     g, o = both(topo, orc, 96, 64)
     sc.load(g)
@@ -901,6 +909,16 @@ def test_timing_slots_select_events(topo, orc):
                 assert tm[k] > 0.0, (names, k)
             else:
                 assert tm[k] == 0.0, (names, k)
+    base = g.counters()
+    for names in (("resolve",), ()):
+        g.set_timing_slots(names, total=False)
+        assert_same_frame(g.render(), want, f"timing slots {names}, no total")
+        tm = g.timings()
+        assert tm["total"] == 0.0 and (tm["resolve"] > 0.0) == ("resolve" in names) and tm["raster"] == 0.0
+        assert g.counters() == base and base["near_blocks"] > 0
+    g.set_timing_slots(None)
+    g.render()
+    assert g.timings()["total"] > 0.0
 
 
 def test_render_device_equals_render(topo, orc):
@@ -989,6 +1007,13 @@ def test_config1_single_tile_small_panorama(topo, orc):
         for k in range(8):
             assert_same_frame((rgba[k], depth[k]), (ro[k], do[k]), f"config-1 mode {mode} sector {k}")
     assert (depth < 1.0).mean() > 0.2
+    # a lone tile around the viewpoint: the host proves that (next to) no block lies beyond the occlusion split, raises the frame's
+    # split above the farthest block and leaves the far phase's four launches out
+    assert not g.debug_far_phase_launched() and g.counters()["far_tested"] == 0
+    g.set_occlusion_split(30000.0)          # ... which a split well inside the tile does not allow
+    rgba2, depth2 = _strip(topo, g, views, sw, sh)
+    assert g.debug_far_phase_launched() and g.counters()["far_tested"] > 0
+    assert np.array_equal(rgba2, rgba) and np.array_equal(depth2.view(np.uint32), depth.view(np.uint32))
 
 
 def test_config3_mosaic25_sector_and_batching(topo, orc):
@@ -1011,6 +1036,7 @@ def test_config3_mosaic25_sector_and_batching(topo, orc):
     for loc in (sc.locs[0], sc.locs[12], sc.locs[24]):
         assert np.array_equal(g.read_normals(*loc), o.read_normals(loc[0], loc[1], tile, tile))
     assert (g.counters()["status"] & 2) == 0
+    assert g.debug_far_phase_launched() and g.counters()["far_tested"] > 0
 
 
 @pytest.fixture(scope="module")

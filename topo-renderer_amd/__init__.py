@@ -91,6 +91,7 @@ def lib():
             "topo_synchronize": (C.c_int, [vp]),
             "topo_set_normals_lds_rows": (C.c_int, [vp, C.c_int]),
             "topo_debug_set_queue_caps": (C.c_int, [vp, u32, u32]),
+            "topo_debug_far_phase_launched": (C.c_int, [vp, vp]),
             "topo_pin_host_buffer": (C.c_int, [vp, vp, sz]),
             "topo_unpin_host_buffer": (C.c_int, [vp, vp]),
             "topo_get_timings": (C.c_int, [vp, vp]),
@@ -520,6 +521,12 @@ class TerrainRenderer:
     def debug_set_queue_caps(self, big_cap: int, rare_cap: int):
         self._check(lib().topo_debug_set_queue_caps(self._h, big_cap, rare_cap))
 
+    def debug_far_phase_launched(self) -> bool:
+        """Whether the last submission launched its far phase (include/topo_hip_test.h)."""
+        out = np.zeros(1, np.int32)
+        self._check(lib().topo_debug_far_phase_launched(self._h, _p(out)))
+        return bool(out[0])
+
     def timings(self) -> dict:
         out = np.zeros(TIMING_SLOTS, np.float32)
         self._check(lib().topo_get_timings(self._h, _p(out)))
@@ -537,9 +544,12 @@ class TerrainRenderer:
         return {"blocks_rastered": int(out[0]) + int(out[5]), "big_items": int(out[1]), "status": int(out[2]), "rare_items": int(out[3]),
                 "near_blocks": int(out[0]), "far_tested": int(out[4]), "far_survived": int(out[5])}   # near/survivors: in strips of 1 or 2 cell rows (terrain_renderer.cpp: near_strip)
 
-    def set_timing_slots(self, names=None):
-        """Measure only the named per-kernel durations (TIMING_NAMES[:6]); None = all, () = just the total."""
+    def set_timing_slots(self, names=None, total=True):
+        """Measure only the named per-kernel durations (TIMING_NAMES[:6]); None = all, () = just the total; total=False: not
+        even that (TOPO_TIMING_NO_TOTAL: no event in front of the frame)."""
         mask = 0x3F if names is None else sum(1 << TIMING_NAMES.index(n) for n in names)
+        if not total:
+            mask |= 0x80
         self._check(lib().topo_set_timing_slots(self._h, mask))
 
     def set_occlusion_split(self, metres: float):

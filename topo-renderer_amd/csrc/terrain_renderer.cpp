@@ -243,6 +243,23 @@ int TerrainRenderer::add_terrain(int32_t lat, int32_t lon, const float* heights,
         if (int rc = run_seam_jobs(edges, corners)) return rc;
     }
     TOPO_HIP_TRY(hipStreamSynchronize(stream_));   // `heights` (and the job lists) are only borrowed for the call
+    {   // the sphere around the block spheres' centres (see Tile::centres); any non-finite entry leaves it unknown
+        std::vector<double> sph((size_t)bxc * byc * 4);
+        TOPO_HIP_TRY(hipMemcpy(sph.data(), nt.dev.block_bounds, sph.size() * sizeof(double), hipMemcpyDeviceToHost));
+        double c[3] = {0.0, 0.0, 0.0}, r2 = 0.0;
+        bool finite = true;
+        for (size_t i = 0; i < sph.size(); i += 4) {
+            finite = finite && std::isfinite(sph[i]) && std::isfinite(sph[i + 1]) && std::isfinite(sph[i + 2]) && std::isfinite(sph[i + 3]);
+            for (int k = 0; k < 3; ++k) c[k] += sph[i + k];
+        }
+        for (int k = 0; k < 3; ++k) c[k] /= (double)(sph.size() / 4);
+        for (size_t i = 0; i < sph.size() && finite; i += 4) {
+            const double dx = sph[i] - c[0], dy = sph[i + 1] - c[1], dz = sph[i + 2] - c[2];
+            r2 = std::max(r2, dx * dx + dy * dy + dz * dz);
+        }
+        nt.centres[0] = c[0]; nt.centres[1] = c[1]; nt.centres[2] = c[2];
+        nt.centres[3] = finite ? std::sqrt(r2) : -1.0;
+    }
     if (had_old) {
         TOPO_HIP_TRY(hipStreamSynchronize(stream_));
         (void)hipFree(old.d_pool);
@@ -454,29 +471,42 @@ int TerrainRenderer::render_frame(FrameCtx& c, hipStream_t stream, uint32_t n, c
         TOPO_HIP_TRY(hipStreamSynchronize(stream));
         overflow_pending_ |= fold_frames(c);
     }
-    // view constants go through a small ring of pinned staging slots, each guarded by an event, so a submission
-    // never has to wait for the stream (pageable sources would force a synchronous staging copy)
+    // View constants.  Up to kPackViews views (a panorama's eight sectors) travel as the argument of a one-workgroup kernel
+    // (k_put_views: the launch copies them; a copy-engine operation and the event guarding its pinned source cost the GPU 13 us
+    // per frame and the host two more calls).  Larger submissions go through a small ring of pinned staging slots, each guarded
+    // by an event, so a submission never has to wait for the stream (pageable sources would force a synchronous staging copy).
+    // Either way each slot has its own device copy, so a later submission cannot overwrite constants a running frame reads.
     if (n > kMaxViewsPerSlot) return fail(TOPO_ERR_INVALID, "too many views in one submission");
-    if (!h_views_) {
-        TOPO_HIP_TRY(hipHostMalloc((void**)&h_views_, sizeof(ViewDev) * kMaxViewsPerSlot * kViewSlots));
-        for (int i = 0; i < kViewSlots; ++i) TOPO_HIP_TRY(hipEventCreateWithFlags(&view_ev_[i], hipEventDisableTiming));
-    }
-    const int slot = view_slot_;
-    view_slot_ = (view_slot_ + 1) % kViewSlots;
-    if (view_used_[slot]) TOPO_HIP_TRY(hipEventSynchronize(view_ev_[slot]));
-    ViewDev* vd = h_views_ + (size_t)slot * kMaxViewsPerSlot;
-    for (uint32_t i = 0; i < n; ++i) {
-        memcpy(vd[i].proj, views[i].camera_proj, sizeof vd[i].proj);
-        vd[i].cam_x = views[i].camera_pos[0];
-        vd[i].cam_y = views[i].camera_pos[1];
-        memcpy(vd[i].sun, views[i].sun_direction, sizeof vd[i].sun);
-        vd[i].view_mode = views[i].view_mode;
-    }
-    // each slot has its own device copy, so a later submission cannot overwrite constants a running frame reads
+    static const bool pack_off = getenv("TOPO_VIEWS_BY_COPY") && atoi(getenv("TOPO_VIEWS_BY_COPY")) != 0;
+    static_assert(kViewSlots % kMaxPipeline == 0, "every frame context has its own share of the slots");
+    // a slot belongs to one frame context, so whatever used it before is ahead of this submission in the same stream
+    const int slot = (int)(&c - ctx_) * (kViewSlots / kMaxPipeline) + (int)(c.frames % (kViewSlots / kMaxPipeline));
     ViewDev* d_slot = (ViewDev*)d_views_ + (size_t)slot * kMaxViewsPerSlot;
-    TOPO_HIP_TRY(hipMemcpyAsync(d_slot, vd, n * sizeof(ViewDev), hipMemcpyHostToDevice, stream));
-    TOPO_HIP_TRY(hipEventRecord(view_ev_[slot], stream));
-    view_used_[slot] = true;
+    auto fill_views = [&](ViewDev* vd) {
+        for (uint32_t i = 0; i < n; ++i) {
+            memcpy(vd[i].proj, views[i].camera_proj, sizeof vd[i].proj);
+            vd[i].cam_x = views[i].camera_pos[0];
+            vd[i].cam_y = views[i].camera_pos[1];
+            memcpy(vd[i].sun, views[i].sun_direction, sizeof vd[i].sun);
+            vd[i].view_mode = views[i].view_mode;
+        }
+    };
+    if (n <= kPackViews && !pack_off) {
+        ViewPack pack{};
+        fill_views(pack.v);
+        launch_put_views(pack, n, d_slot, stream);
+    } else {
+        if (!h_views_) {
+            TOPO_HIP_TRY(hipHostMalloc((void**)&h_views_, sizeof(ViewDev) * kMaxViewsPerSlot * kViewSlots));
+            for (int i = 0; i < kViewSlots; ++i) TOPO_HIP_TRY(hipEventCreateWithFlags(&view_ev_[i], hipEventDisableTiming));
+        }
+        if (view_used_[slot]) TOPO_HIP_TRY(hipEventSynchronize(view_ev_[slot]));
+        ViewDev* vd = h_views_ + (size_t)slot * kMaxViewsPerSlot;
+        fill_views(vd);
+        TOPO_HIP_TRY(hipMemcpyAsync(d_slot, vd, n * sizeof(ViewDev), hipMemcpyHostToDevice, stream));
+        TOPO_HIP_TRY(hipEventRecord(view_ev_[slot], stream));
+        view_used_[slot] = true;
+    }
 
     FrameParams p{};
     p.tiles = (const TileDev*)d_tiles_;
@@ -486,6 +516,16 @@ int TerrainRenderer::render_frame(FrameCtx& c, hipStream_t stream, uint32_t n, c
     p.work = (WorkItem*)c.d_work;
     // this frame's counter set; the other one is zeroed by this frame's clear for the next frame of the context
     p.counters = (uint32_t*)c.d_counters + (c.frames & 1u) * kCounterWords;
+    // this frame's counters (queue fills, status bits), for whoever waits for the frame (check_frames, get_counters): stored by
+    // k_resolve into the pinned ring.  The bounds-checking build, whose k_resolve may still set a status bit, copies them
+    // behind the frame instead.
+    uint32_t* const h_status_slot = c.h_status + (c.submitted % kStatusRing) * 16;
+#if defined(TOPO_BOUNDS_CHECK) || defined(TOPO_RESOLVE_PROF)
+    p.status_out = nullptr;
+#else
+    static const bool status_copy = getenv("TOPO_STATUS_BY_COPY") && atoi(getenv("TOPO_STATUS_BY_COPY")) != 0;
+    p.status_out = status_copy ? nullptr : h_status_slot;
+#endif
     uint32_t* const counters_next = (uint32_t*)c.d_counters + ((c.frames & 1u) ^ 1u) * kCounterWords;
     p.big = (BigItem*)c.d_big;
     p.rare = (RareItem*)c.d_rare;
@@ -523,6 +563,32 @@ int TerrainRenderer::render_frame(FrameCtx& c, hipStream_t stream, uint32_t n, c
                    (to_unorm8(1.0f) << 24);
     }
     last_blocks_tested_ = (uint32_t)work_cap;
+    // Is the far phase worth its four launches (each ~4 us of GPU and ~9 us of host time)?  k_cull makes an occlusion-test
+    // candidate of a block whose nearest possible view depth, w(centre) - radius |w row|, exceeds the split;
+    // w(centre) <= w(C) + R |w row| for the sphere (C, R) around the tile's block centres (Tile::centres).  The split is a
+    // performance knob with a flat optimum (60..120 km at c4; results do not depend on it): when that bound stays below 4/3 of
+    // it for every view and tile -- a lone tile around the viewpoint -- the frame's split is raised above the bound, no block
+    // becomes a candidate and the far phase is not launched.
+    bool far_phase = p.split_m > 0.0f;
+    static const bool far_skip_off = getenv("TOPO_FAR_SKIP") && atoi(getenv("TOPO_FAR_SKIP")) == 0;
+    if (far_phase && !far_skip_off) {
+        double bound = 0.0;
+        for (uint32_t i = 0; i < n && bound >= 0.0; ++i) {
+            const float* m = views[i].camera_proj;
+            const double wn = std::sqrt((double)m[3] * m[3] + (double)m[7] * m[7] + (double)m[11] * m[11]);
+            for (const auto& kv : tiles_) {
+                const double* s = kv.second.centres;
+                const double w_far = (double)m[3] * s[0] + (double)m[7] * s[1] + (double)m[11] * s[2] + (double)m[15] + s[3] * wn;
+                if (!(s[3] >= 0.0) || !(w_far < 1e30)) { bound = -1.0; break; }      // unknown sphere, NaN or huge: keep the far phase
+                bound = std::max(bound, w_far);
+            }
+        }
+        if (bound >= 0.0 && bound + 2.0 < (double)p.split_m * (4.0 / 3.0)) {
+            p.split_m = std::max(p.split_m, (float)(bound + 2.0));      // (>= bound + 1 after the rounding to f32: no candidates)
+            far_phase = false;
+        }
+    }
+    last_far_phase_ = far_phase;
 
     // clear -> cull -> [near blocks: raster, rare, big] -> occlusion test of the far blocks -> [survivors: raster,
     // rare, big] -> resolve.  Event slots: 0 clear, 1 cull, 2 raster(near), 3 rare+big(near), 4 occlusion,
@@ -530,7 +596,7 @@ int TerrainRenderer::render_frame(FrameCtx& c, hipStream_t stream, uint32_t n, c
     // A timing event between two kernels costs ~6 us of idle GPU (the next kernel waits for the marker), so only the
     // events the selected timing slots need are recorded (topo_set_timing_slots); slot -> stages: 0:{0} 1:{1} 2:{2,5} 3:{4}
     // 4:{3,6} 5:{7}, stage i = ev[i]..ev[i+1]; the total (ev[0], ev[8]) is always kept.
-    uint32_t ev_need = 0x101u;
+    uint32_t ev_need = timing_total_ ? 0x101u : 0u;
     {
         static const uint32_t stages_of_slot[6] = {1u << 0, 1u << 1, (1u << 2) | (1u << 5), 1u << 4, (1u << 3) | (1u << 6), 1u << 7};
         for (int sl = 0; sl < 6; ++sl)
@@ -538,19 +604,26 @@ int TerrainRenderer::render_frame(FrameCtx& c, hipStream_t stream, uint32_t n, c
                 for (int st = 0; st < 8; ++st)
                     if (stages_of_slot[sl] & (1u << st)) ev_need |= (3u << st);
     }
+    // With nothing but k_resolve's duration and / or the total selected (bench.py's timed region) the events are not markers between
+    // the kernels but the kernels' own start and end times (hipExtLaunchKernel: ev[0] = start of the frame's first kernel, ev[7] /
+    // ev[8] = start / end of k_resolve): a pair of markers costs a frame 8-10 us, these next to nothing.
+    const bool pixelize = post_.pixelize_n < 99.99999f;
+    static const bool markers_only = getenv("TOPO_EVENTS_BY_MARKER") && atoi(getenv("TOPO_EVENTS_BY_MARKER")) != 0;
+    const bool own_times = !markers_only && !pixelize && (timing_slots_ & ~(1u << 5)) == 0;
     const int ring = (int)(c.frames % kEvRing);
     hipEvent_t* const ev = c.evr[ring];
     c.evr_recorded[ring] = ev_need;
     c.evr_slots[ring] = timing_slots_;
     c.evr_frame[ring] = ++frame_seq_;
     ++c.frames;
-    if (ev_need & (1u << 0)) TOPO_HIP_TRY(hipEventRecord(ev[0], stream));
+    if ((ev_need & (1u << 0)) && !own_times) TOPO_HIP_TRY(hipEventRecord(ev[0], stream));
+    const hipEvent_t ev_first = (ev_need & (1u << 0)) && own_times ? ev[0] : nullptr;
     // clear and cull side by side in one launch (timing slot "clear" then holds both, "cull" nothing); TOPO_FUSE_CLEAR_CULL=0 or
     // an empty tile set: one after the other
     static const bool fuse_off = getenv("TOPO_FUSE_CLEAR_CULL") && atoi(getenv("TOPO_FUSE_CLEAR_CULL")) == 0;
     const bool fuse = !fuse_off && n_tiles != 0;
-    if (fuse) launch_clear_cull(p, counters_next, stream);
-    else launch_clear(p, counters_next, stream);
+    if (fuse) launch_clear_cull(p, counters_next, stream, ev_first);
+    else launch_clear(p, counters_next, stream, ev_first);
     if (ev_need & (1u << 1)) TOPO_HIP_TRY(hipEventRecord(ev[1], stream));
     if (!fuse) launch_cull(p, stream);
     if (ev_need & (1u << 2)) TOPO_HIP_TRY(hipEventRecord(ev[2], stream));
@@ -559,21 +632,21 @@ int TerrainRenderer::render_frame(FrameCtx& c, hipStream_t stream, uint32_t n, c
     launch_raster_rare(p, stream);
     launch_raster_big(p, stream);
     if (ev_need & (1u << 4)) TOPO_HIP_TRY(hipEventRecord(ev[4], stream));
-    if (p.split_m > 0.0f) {
+    if (far_phase) {
         launch_occlusion(p, stream);
     }
     if (ev_need & (1u << 5)) TOPO_HIP_TRY(hipEventRecord(ev[5], stream));
-    if (p.split_m > 0.0f) launch_raster(p, 1, stream);
+    if (far_phase) launch_raster(p, 1, stream);
     if (ev_need & (1u << 6)) TOPO_HIP_TRY(hipEventRecord(ev[6], stream));
-    if (p.split_m > 0.0f) {
+    if (far_phase) {
         launch_raster_rare(p, stream);
         launch_raster_big(p, stream);
     }
-    if (ev_need & (1u << 7)) TOPO_HIP_TRY(hipEventRecord(ev[7], stream));
+    if ((ev_need & (1u << 7)) && !own_times) TOPO_HIP_TRY(hipEventRecord(ev[7], stream));
+    const hipEvent_t ev_rstart = (ev_need & (1u << 7)) && own_times ? ev[7] : nullptr, ev_rstop = (ev_need & (1u << 8)) && own_times ? ev[8] : nullptr;
     // The pixelise branch of the post shader (pixelize_n < 99.99999; the reference never takes it) samples the render target
     // away from the pixel's own texel: k_resolve then stores the render-target texels into an image of the context's
     // (post_off) and k_post_pixelize makes the surface image from it and the depth image.
-    const bool pixelize = post_.pixelize_n < 99.99999f;
     OutputParams kout = out;
     if (pixelize) {
         if (n_slots) return fail(TOPO_ERR_UNSUPPORTED, "the pixelise branch is not available on the slot-by-slot (multi-GPU) path");
@@ -590,7 +663,7 @@ int TerrainRenderer::render_frame(FrameCtx& c, hipStream_t stream, uint32_t n, c
     if (n_slots == 0) {
         p.rblock_first = 0;
         p.rblock_count = p.rblocks_view * n;
-        launch_resolve(p, kout, stream);
+        launch_resolve(p, kout, stream, ev_rstart, ev_rstop);
         if (pixelize)
             launch_post_pixelize(n, (int32_t)w, (int32_t)h, post_.viewport[0] >= 1.0f ? post_.viewport[0] : (float)w, post_.viewport[1] >= 1.0f ? post_.viewport[1] : (float)h,
                                  post_.pixelize_n, (const uint8_t*)d_pre_rgba_, out, kout.depth, kout.depth_view_stride, kout.depth_pitch, p.linear_target, p.bgra, stream);
@@ -599,14 +672,13 @@ int TerrainRenderer::render_frame(FrameCtx& c, hipStream_t stream, uint32_t n, c
             if ((uint64_t)slots[i].block_first + slots[i].block_count > (uint64_t)p.rblocks_view * n) return fail(TOPO_ERR_INVALID, "resolve slot outside the frame");
             p.rblock_first = slots[i].block_first;
             p.rblock_count = slots[i].block_count;
-            launch_resolve(p, out, stream);
+            launch_resolve(p, out, stream, i == 0 ? ev_rstart : nullptr, i + 1 == n_slots ? ev_rstop : nullptr);
             if (after_slot)
                 if (int rc = (*after_slot)(i, stream)) return rc;
         }
     }
-    if (ev_need & (1u << 8)) TOPO_HIP_TRY(hipEventRecord(ev[8], stream));
-    // this frame's counters (queue fills, status bits), for whoever waits for the frame (check_frames, get_counters)
-    TOPO_HIP_TRY(hipMemcpyAsync(c.h_status + (c.submitted % kStatusRing) * 16, p.counters, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    if ((ev_need & (1u << 8)) && !own_times) TOPO_HIP_TRY(hipEventRecord(ev[8], stream));
+    if (!p.status_out) TOPO_HIP_TRY(hipMemcpyAsync(h_status_slot, p.counters, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     ++c.submitted;
     c.timed = true;
     TOPO_HIP_TRY(hipGetLastError());
@@ -909,6 +981,7 @@ int TerrainRenderer::set_normals_lds_rows(int rows) {
 
 int TerrainRenderer::set_timing_slots(uint32_t mask) {
     timing_slots_ = mask & 0x3Fu;
+    timing_total_ = !(mask & TOPO_TIMING_NO_TOTAL);
     return TOPO_OK;
 }
 
@@ -942,7 +1015,8 @@ int TerrainRenderer::frame_durations(FrameCtx& c, int ring, float out[7]) {
     out[5] = d[7];                // resolve
     for (int sl = 0; sl < 6; ++sl)
         if (!(c.evr_slots[ring] & (1u << sl))) out[sl] = 0.0f;      // (a neighbour's events may have bracketed it by chance)
-    TOPO_HIP_TRY(hipEventElapsedTime(&out[6], ev[0], ev[8]));
+    out[6] = 0.0f;
+    if ((c.evr_recorded[ring] & 0x101u) == 0x101u) TOPO_HIP_TRY(hipEventElapsedTime(&out[6], ev[0], ev[8]));
     return TOPO_OK;
 }
 
@@ -954,7 +1028,8 @@ int TerrainRenderer::get_timings(float out[TOPO_TIMING_SLOTS]) {
     FrameCtx& c = ctx_[pipeline_depth_ > 1 ? next_ctx_ : last_ctx_];
     if (c.timed && c.frames) {
         const int ring = (int)((c.frames - 1) % kEvRing);
-        TOPO_HIP_TRY(hipEventSynchronize(c.evr[ring][8]));
+        if (c.evr_recorded[ring] & 0x100u) TOPO_HIP_TRY(hipEventSynchronize(c.evr[ring][8]));
+        else TOPO_HIP_TRY(hipStreamSynchronize(pipeline_depth_ > 1 ? c.stream : stream_));      // (TOPO_TIMING_NO_TOTAL: no event behind the frame)
         if (int rc = frame_durations(c, ring, out)) return rc;
     }
     if (load_timed_) {

@@ -37,6 +37,9 @@ struct Tile {          // RenderBuffer (render_buffer.rs:23-31) minus the wgpu p
     uint32_t* d_normals = nullptr;
     float* d_minmax = nullptr;
     void* d_pool = nullptr;         // the one allocation the three pointers above point into
+    // a sphere around the centres of the tile's block spheres (the cull's load-time table, read back once per tile): lets a
+    // submission prove on the host that none of its blocks can be an occlusion-test candidate.  radius < 0: unknown.
+    double centres[4] = {0.0, 0.0, 0.0, -1.0};
     TileDev dev{};
 };
 
@@ -48,6 +51,7 @@ class TerrainRenderer {
     int add_terrain(int32_t lat, int32_t lon, const float* heights, bool heights_on_device, uint32_t w, uint32_t h,
                     const float rp[2], const float mp[2], const float ps[2]);
     int unload_terrain(int32_t lat, int32_t lon);
+    bool last_far_phase() const { return last_far_phase_; }
     int update(uint32_t w, uint32_t h, const topo_uniforms* u, const topo_post_uniforms* pu);
     int render(uint8_t* rgba, size_t rgba_pitch, float* depth, size_t depth_pitch);
     int render_views_device(uint32_t n, const topo_uniforms* views, uint32_t w, uint32_t h, const OutputParams& out);
@@ -125,6 +129,7 @@ class TerrainRenderer {
     uint32_t big_cap_cfg_ = 0, rare_cap_cfg_ = 0;
     uint64_t rare_cap_auto_ = 0;           // rare-queue capacity topo_render grew to after an overflow (0 = default)
     uint32_t timing_slots_ = 0x3Fu;        // topo_set_timing_slots: which per-kernel durations to measure
+    bool timing_total_ = true;        // ev[0] and ev[8] (TOPO_TIMING_NO_TOTAL clears it)
     float occlusion_split_m_ = 90000.0f;   // flat optimum 60..120 km at c4 (profiles/README.md)
 
     hipStream_t own_stream_ = nullptr, stream_ = nullptr;
@@ -196,7 +201,6 @@ class TerrainRenderer {
     ViewDev* h_views_ = nullptr;          // pinned staging ring
     hipEvent_t view_ev_[kViewSlots] = {};
     bool view_used_[kViewSlots] = {};
-    int view_slot_ = 0;
     void* d_peaks_ = nullptr;    size_t cap_peaks_ = 0;      // xyz in, then visible + xy out
     void* d_proj_ = nullptr;     size_t cap_proj_ = 0;
     void* d_overlay_geo_ = nullptr;  size_t cap_overlay_geo_ = 0;     // overlay vertices + indices
@@ -205,6 +209,7 @@ class TerrainRenderer {
     bool have_depth_ = false;
     uint32_t depth_w_ = 0, depth_h_ = 0;
     uint32_t last_blocks_tested_ = 0;
+    bool last_far_phase_ = true;           // whether the last submission launched the far phase (test hook)
 
     std::string err_;
 };

@@ -127,6 +127,13 @@ int topo_debug_set_queue_caps(topo_ctx* ctx, uint32_t big_cap, uint32_t rare_cap
     TOPO_CALL(ctx->r->set_queue_caps(big_cap, rare_cap));
 }
 
+int topo_debug_far_phase_launched(topo_ctx* ctx, int32_t* out) {
+    TOPO_GUARD(ctx);
+    if (!out) return TOPO_ERR_INVALID;
+    *out = ctx->r->last_far_phase() ? 1 : 0;
+    return TOPO_OK;
+}
+
 int topo_get_timings(topo_ctx* ctx, float out_ms[TOPO_TIMING_SLOTS]) {
     TOPO_GUARD(ctx);
     TOPO_CALL(ctx->r->get_timings(out_ms));

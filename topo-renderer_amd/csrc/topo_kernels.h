@@ -2,6 +2,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include "topo_pipeline.h"
 
@@ -51,6 +52,8 @@ struct FrameParams {
     uint32_t* counters;        // [0] near work count, [1] big count, [2] status bits, [3] rare count, [4] far candidates,
                                // [5] far survivors, [6] big start, [7] rare start (of the current phase), [8..10] first
                                // bounds violation (check build); 16 words; two sets per frame context, alternating: a frame's set was zeroed by the clear of the frame before
+    uint32_t* status_out;      // pinned host memory, or null: k_resolve's first workgroup stores the frame's 16 counter words there (nothing
+                               // changes them once the raster kernels are done), instead of a copy operation behind the frame
     BigItem* big;
     RareItem* rare;
     FarItem* far;              // far candidates (k_cull -> k_occlusion)
@@ -120,14 +123,21 @@ void launch_normals_border(const TileDev* tiles, const EdgeJob* edges, uint32_t 
 
 // frame phase (render)
 // `zero`: the counter set of the NEXT frame (the two sets of a frame context alternate), zeroed by the clear
-void launch_clear(const FrameParams& p, uint32_t* zero, hipStream_t s);        // re-initialises the marked segments
-void launch_clear_cull(const FrameParams& p, uint32_t* zero, hipStream_t s);   // the clear and the cull in one launch, side by side
+// A submission's view constants travel as a kernel argument (up to kPackViews views = 704 bytes): the launch copies them, so the
+// caller's array is free at once and no staging slot, copy-engine operation or event stands in front of the frame.
+constexpr uint32_t kPackViews = 8;
+struct ViewPack { ViewDev v[kPackViews]; };
+void launch_put_views(const ViewPack& pack, uint32_t n, ViewDev* dst, hipStream_t s);
+// (`start` / `stop`, where a launcher has them: events that take the kernel's own start / end time -- hipExtLaunchKernel: the
+// dispatch's completion signal carries both, no marker packet stands between two kernels)
+void launch_clear(const FrameParams& p, uint32_t* zero, hipStream_t s, hipEvent_t start = nullptr);        // re-initialises the marked segments
+void launch_clear_cull(const FrameParams& p, uint32_t* zero, hipStream_t s, hipEvent_t start = nullptr);   // the clear and the cull in one launch, side by side
 void launch_cull(const FrameParams& p, hipStream_t s);
 void launch_raster(const FrameParams& p, int phase, hipStream_t s);   // phase 0: near list, 1: far survivors
 void launch_occlusion(const FrameParams& p, hipStream_t s);
 void launch_raster_rare(const FrameParams& p, hipStream_t s);
 void launch_raster_big(const FrameParams& p, hipStream_t s);
-void launch_resolve(const FrameParams& p, const OutputParams& o, hipStream_t s);
+void launch_resolve(const FrameParams& p, const OutputParams& o, hipStream_t s, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
 
 // overlay pass (line_shader.wgsl over the post pass's image): keys = W*H overlay keys, (re-)initialised when keys_fresh
 void launch_overlay(const OverlayVertex* verts, const uint32_t* idx, uint32_t n_tris, uint32_t n_verts, float width, int32_t W, int32_t H, uint64_t* keys,

@@ -1519,6 +1519,9 @@ __global__ __launch_bounds__(256, TOPO_RESOLVE_WGS) void k_resolve(FrameParams P
 #pragma unroll
     for (int k = 0; k < 4; ++k) s_lut[threadIdx.x + 256 * k] = TOPO_SRGB_LUT12_WORDS[threadIdx.x + 256 * k];
     const uint8_t* lut = reinterpret_cast<const uint8_t*>(s_lut);
+    // the frame's counters (queue fills, status bits) for whoever waits for the frame: final since the last raster kernel, stored to
+    // the host's pinned ring from here (a copy operation behind the frame was a blit kernel of its own: ~10 us of every frame)
+    if (P.status_out && blockIdx.x == 0 && threadIdx.x < 16) P.status_out[threadIdx.x] = P.counters[threadIdx.x];
     __syncthreads();                   // the only barrier
 #ifdef TOPO_RESOLVE_PROF      // experiment build: where do a wave's cycles go?  counters[8..15], units of 1024 cycles summed over waves
     uint32_t pf_t = (uint32_t)__builtin_amdgcn_s_memtime(), pf_acc[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -2178,14 +2181,27 @@ void launch_normals_border(const TileDev* tiles, const EdgeJob* edges, uint32_t 
     hipLaunchKernelGGL(k_normals_border, dim3(blocks), dim3(64), 0, s, tiles, edges, n_edges, chunks, corners, n_corners, (int)w, (int)h);
 }
 
-void launch_clear(const FrameParams& p, uint32_t* zero, hipStream_t s) {
+void launch_clear(const FrameParams& p, uint32_t* zero, hipStream_t s, hipEvent_t start) {
     const size_t n = (size_t)p.n_views * p.W * p.H;
-    hipLaunchKernelGGL(k_clear, dim3(2048), dim3(256), 0, s, p.vis, p.dirty, n, p.counters, zero);
+    if (start) hipExtLaunchKernelGGL(k_clear, dim3(2048), dim3(256), 0, s, start, nullptr, 0, p.vis, p.dirty, n, p.counters, zero);
+    else hipLaunchKernelGGL(k_clear, dim3(2048), dim3(256), 0, s, p.vis, p.dirty, n, p.counters, zero);
 }
-void launch_clear_cull(const FrameParams& p, uint32_t* zero, hipStream_t s) {
+// The view constants of a submission, from the kernel's own argument segment into the device slot the frame's kernels read.
+__global__ __launch_bounds__(256) void k_put_views(ViewPack pack, uint32_t n_words, uint32_t* __restrict__ dst) {
+    static_assert(sizeof(ViewPack) % 4 == 0 && sizeof(ViewPack) / 4 <= 256, "one word per lane");
+    const auto src = (const __attribute__((address_space(4))) uint32_t*)__builtin_amdgcn_kernarg_segment_ptr();      // `pack` is the first argument
+    if (threadIdx.x < n_words) dst[threadIdx.x] = src[threadIdx.x];
+}
+
+void launch_put_views(const ViewPack& pack, uint32_t n, ViewDev* dst, hipStream_t s) {
+    hipLaunchKernelGGL(k_put_views, dim3(1), dim3(256), 0, s, pack, n * (uint32_t)(sizeof(ViewDev) / 4), (uint32_t*)dst);
+}
+
+void launch_clear_cull(const FrameParams& p, uint32_t* zero, hipStream_t s, hipEvent_t start) {
     const size_t total = (size_t)p.n_views * p.n_tiles * p.bx_count * p.by_count;
     const unsigned n_cull = (unsigned)((total + 255) / 256), n_clear = 2048;
-    hipLaunchKernelGGL(k_clear_cull, dim3(n_cull + n_clear), dim3(256), 0, s, p, n_cull, n_clear, zero);
+    if (start) hipExtLaunchKernelGGL(k_clear_cull, dim3(n_cull + n_clear), dim3(256), 0, s, start, nullptr, 0, p, n_cull, n_clear, zero);
+    else hipLaunchKernelGGL(k_clear_cull, dim3(n_cull + n_clear), dim3(256), 0, s, p, n_cull, n_clear, zero);
 }
 
 void launch_cull(const FrameParams& p, hipStream_t s) {
@@ -2235,7 +2251,7 @@ void launch_raster_big(const FrameParams& p, hipStream_t s) {
     hipLaunchKernelGGL(k_raster_big, dim3(grid), dim3(256), 0, s, p);
 }
 
-void launch_resolve(const FrameParams& p, const OutputParams& o, hipStream_t s) {
+void launch_resolve(const FrameParams& p, const OutputParams& o, hipStream_t s, hipEvent_t start, hipEvent_t stop) {
     const unsigned n_blocks = p.rblock_count;
     if (n_blocks == 0) return;
     // four times the resident workgroups: the hardware then hands out workgroups as others finish, which evens out what the
@@ -2245,10 +2261,14 @@ void launch_resolve(const FrameParams& p, const OutputParams& o, hipStream_t s) 
     if (const char* e = getenv("TOPO_RESOLVE_GRID")) resident = (unsigned)atoi(e) ? (unsigned)atoi(e) : n_blocks;      // experiments: 0 = one block per workgroup
     const dim3 grid(n_blocks < resident ? n_blocks : resident), block(256);
     const bool bgra = p.bgra && !p.post_off;      // (the render-target image of the pixelise path is always R G B A)
-    if (!p.linear_target && !bgra) hipLaunchKernelGGL((k_resolve<true, false>), grid, block, 0, s, p, o);
-    else if (!p.linear_target) hipLaunchKernelGGL((k_resolve<true, true>), grid, block, 0, s, p, o);
-    else if (!bgra) hipLaunchKernelGGL((k_resolve<false, false>), grid, block, 0, s, p, o);
-    else hipLaunchKernelGGL((k_resolve<false, true>), grid, block, 0, s, p, o);
+    auto launch = [&](auto kernel) {
+        if (start || stop) hipExtLaunchKernelGGL(kernel, grid, block, 0, s, start, stop, 0, p, o);
+        else hipLaunchKernelGGL(kernel, grid, block, 0, s, p, o);
+    };
+    if (!p.linear_target && !bgra) launch(k_resolve<true, false>);
+    else if (!p.linear_target) launch(k_resolve<true, true>);
+    else if (!bgra) launch(k_resolve<false, false>);
+    else launch(k_resolve<false, true>);
 }
 
 void launch_overlay(const OverlayVertex* verts, const uint32_t* idx, uint32_t n_tris, uint32_t n_verts, float width, int32_t W, int32_t H, uint64_t* keys,
