@@ -2194,11 +2194,8 @@ __global__ __launch_bounds__(256) void k_put_views(ViewPack pack, uint32_t n_wor
 }
 
 void launch_put_views(const ViewPack& pack, uint32_t n, ViewDev* dst, hipStream_t s) {
-    // (it waits for nothing -- its slot is not one a frame in flight reads -- so it is launched out of order: hipExtAnyOrderLaunch takes
-    // the barrier off the dispatch and the 3.6 us of this launch pass under the tail of the frame before)
-    static const bool in_order = getenv("TOPO_PUT_VIEWS_IN_ORDER") && atoi(getenv("TOPO_PUT_VIEWS_IN_ORDER")) != 0;
-    if (in_order) hipLaunchKernelGGL(k_put_views, dim3(1), dim3(256), 0, s, pack, n * (uint32_t)(sizeof(ViewDev) / 4), (uint32_t*)dst);
-    else hipExtLaunchKernelGGL(k_put_views, dim3(1), dim3(256), 0, s, nullptr, nullptr, hipExtAnyOrderLaunch, pack, n * (uint32_t)(sizeof(ViewDev) / 4), (uint32_t*)dst);
+    // (hipExtAnyOrderLaunch, which would let this launch pass under the tail of the frame before, is not honoured on gfx9: measured, no change)
+    hipLaunchKernelGGL(k_put_views, dim3(1), dim3(256), 0, s, pack, n * (uint32_t)(sizeof(ViewDev) / 4), (uint32_t*)dst);
 }
 
 void launch_clear_cull(const FrameParams& p, uint32_t* zero, hipStream_t s, hipEvent_t start) {
