@@ -420,12 +420,8 @@ def main():
         r.set_pipeline_depth(1)
         del outs2
 
-    # ---- CPU baseline: the oracle (a C++ port of the reference's shaders + raster semantics; the reference's
-    # own wgpu CPU-adapter path cannot be built here) on a bounded sample, rank 0 at N=1 only.
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(T, np, locs, vlat, vlon, views, SW, PH, args.cpu_threads)
-
-    # ---- the drop-in entry point hands back HOST buffers: its PCIe-inclusive rate (never `value`), one sector-sized frame
+    # ---- the drop-in entry point hands back HOST buffers: its PCIe-inclusive rate (never `value`; measured before the CPU baseline,
+    # whose OpenMP threads keep spinning on the cores for a while after their last region), one sector-sized frame
     # (RGBA8 + pad_256-pitched depth) per call: into fresh pageable arrays (through the context's pinned staging image) and
     # into arrays the caller pinned once (topo_pin_host_buffer: direct copies)
     if rank == 0 and world == 1 and not args.no_host_path:
@@ -436,12 +432,16 @@ def main():
         hdepth = np.zeros((PH, T.pad_256(4 * SW) // 4), np.float32)
         nbytes = hrgba.nbytes + hdepth.nbytes
 
-        def timed(n=5):
+        def timed(n=5, batches=3):      # best of three batches of five calls (the host's copy threads share the box's cores with whatever else runs there)
             r.render_into(hrgba, hdepth)
-            t1 = time.perf_counter()
-            for _ in range(n):
-                r.render_into(hrgba, hdepth)
-            return (time.perf_counter() - t1) / n
+            best = None
+            for _ in range(batches):
+                t1 = time.perf_counter()
+                for _ in range(n):
+                    r.render_into(hrgba, hdepth)
+                dt = (time.perf_counter() - t1) / n
+                best = dt if best is None or dt < best else best
+            return best
         dt_staged = timed()
         r.pin_host_buffer(hrgba)
         r.pin_host_buffer(hdepth)
@@ -454,6 +454,11 @@ def main():
                          "how": "pinned staging image of the context, slices copied on by host threads"},
             "pinned_by_caller": {"ms": round(dt_pinned * 1e3, 3), "GBps": round(nbytes / dt_pinned / 1e9, 1), "mpix_s": round(SW * PH / 1e6 / dt_pinned, 1),
                                  "how": "topo_pin_host_buffer: direct copies"}}
+
+    # ---- CPU baseline: the oracle (a C++ port of the reference's shaders + raster semantics; the reference's
+    # own wgpu CPU-adapter path cannot be built here) on a bounded sample, rank 0 at N=1 only.
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(T, np, locs, vlat, vlon, views, SW, PH, args.cpu_threads)
 
     if args.check and rank == 0:
         mine = strip[my[0]:my[0] + per]
