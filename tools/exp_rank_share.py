@@ -22,7 +22,7 @@ eye = T.geometry_transform(ground + 50.0, vlon, vlat)
 views = T.panorama_uniforms(eye, 0.0, SW, PH, vlon, vlat, 0)
 rgba = torch.empty((8, PH, SW, 4), dtype=torch.uint8, device="cuda")
 depth = torch.empty((8, PH, SW), dtype=torch.float32, device="cuda")
-r.set_timing_slots(())
+r.set_timing_slots((), total=False)
 VS = PH * SW * 4
 for n_ranks in (1, 2, 4, 8):
     per = 8 // n_ranks
