@@ -491,10 +491,16 @@ int TerrainRenderer::render_frame(FrameCtx& c, hipStream_t stream, uint32_t n, c
             vd[i].view_mode = views[i].view_mode;
         }
     };
-    if (n <= kPackViews && !pack_off) {
-        ViewPack pack{};
+    // (with the frame's first kernel being k_clear_cull -- there are tiles to cull -- the pack rides in THAT launch's argument
+    // segment: no upload kernel either; TOPO_VIEWS_IN_CULL=0: always k_put_views)
+    static const bool fuse_off = getenv("TOPO_FUSE_CLEAR_CULL") && atoi(getenv("TOPO_FUSE_CLEAR_CULL")) == 0;
+    static const bool in_cull_off = getenv("TOPO_VIEWS_IN_CULL") && atoi(getenv("TOPO_VIEWS_IN_CULL")) == 0;
+    const bool fuse = !fuse_off && n_tiles != 0;
+    ViewPack pack{};
+    const bool packed = n <= kPackViews && !pack_off, pack_in_cull = packed && fuse && !in_cull_off;
+    if (packed) {
         fill_views(pack.v);
-        launch_put_views(pack, n, d_slot, stream);
+        if (!pack_in_cull) launch_put_views(pack, n, d_slot, stream);
     } else {
         if (!h_views_) {
             TOPO_HIP_TRY(hipHostMalloc((void**)&h_views_, sizeof(ViewDev) * kMaxViewsPerSlot * kViewSlots));
@@ -620,9 +626,7 @@ int TerrainRenderer::render_frame(FrameCtx& c, hipStream_t stream, uint32_t n, c
     const hipEvent_t ev_first = (ev_need & (1u << 0)) && own_times ? ev[0] : nullptr;
     // clear and cull side by side in one launch (timing slot "clear" then holds both, "cull" nothing); TOPO_FUSE_CLEAR_CULL=0 or
     // an empty tile set: one after the other
-    static const bool fuse_off = getenv("TOPO_FUSE_CLEAR_CULL") && atoi(getenv("TOPO_FUSE_CLEAR_CULL")) == 0;
-    const bool fuse = !fuse_off && n_tiles != 0;
-    if (fuse) launch_clear_cull(p, counters_next, stream, ev_first);
+    if (fuse) launch_clear_cull(p, counters_next, stream, ev_first, pack_in_cull ? &pack : nullptr, n);
     else launch_clear(p, counters_next, stream, ev_first);
     if (ev_need & (1u << 1)) TOPO_HIP_TRY(hipEventRecord(ev[1], stream));
     if (!fuse) launch_cull(p, stream);

@@ -131,7 +131,7 @@ void launch_put_views(const ViewPack& pack, uint32_t n, ViewDev* dst, hipStream_
 // (`start` / `stop`, where a launcher has them: events that take the kernel's own start / end time -- hipExtLaunchKernel: the
 // dispatch's completion signal carries both, no marker packet stands between two kernels)
 void launch_clear(const FrameParams& p, uint32_t* zero, hipStream_t s, hipEvent_t start = nullptr);        // re-initialises the marked segments
-void launch_clear_cull(const FrameParams& p, uint32_t* zero, hipStream_t s, hipEvent_t start = nullptr);   // the clear and the cull in one launch, side by side
+void launch_clear_cull(const FrameParams& p, uint32_t* zero, hipStream_t s, hipEvent_t start = nullptr, const ViewPack* pack = nullptr, uint32_t n_pack_views = 0);   // the clear and the cull in one launch, side by side
 void launch_cull(const FrameParams& p, hipStream_t s);
 void launch_raster(const FrameParams& p, int phase, hipStream_t s);   // phase 0: near list, 1: far survivors
 void launch_occlusion(const FrameParams& p, hipStream_t s);

@@ -814,7 +814,25 @@ __global__ __launch_bounds__(256) void k_cull(FrameParams P) { cull_body(P, bloc
 // frame's counters, the cull reads the load-time tables and appends through this frame's counters), one is bound by its
 // stores, the other by f64 arithmetic and gathers -- side by side they take what the clear takes alone (c4: 0.046 + 0.031 ->
 // 0.05 ms).
-__global__ __launch_bounds__(256) void k_clear_cull(FrameParams P, uint32_t n_cull_blocks, uint32_t n_clear_blocks, uint32_t* __restrict__ zero) {
+// `pack_words` != 0: the submission's view constants ride in this launch's own argument segment (`pack`: up to kPackViews views, 22
+// words each).  The cull reads them there -- the segment is ordinary device-visible memory behind a constant-address-space pointer --
+// and the launch's first workgroup copies them into the device slot the frame's later kernels read (P.views): no upload in front of
+// the frame, not even a kernel's.
+struct ClearCullArgs {          // the kernel's parameter list as the argument segment lays it out (natural alignment, in order)
+    FrameParams P;
+    uint32_t n_cull_blocks, n_clear_blocks;
+    uint32_t* zero;
+    ViewPack pack;
+    uint32_t pack_words;
+};
+__global__ __launch_bounds__(256) void k_clear_cull(FrameParams P, uint32_t n_cull_blocks, uint32_t n_clear_blocks, uint32_t* __restrict__ zero, ViewPack pack,
+                                                    uint32_t pack_words) {
+    const auto seg = (const __attribute__((address_space(4))) uint8_t*)__builtin_amdgcn_kernarg_segment_ptr();
+    if (pack_words) {
+        const auto src = (const __attribute__((address_space(4))) uint32_t*)(seg + offsetof(ClearCullArgs, pack));
+        if (blockIdx.x == 0 && threadIdx.x < pack_words) const_cast<uint32_t*>(reinterpret_cast<const uint32_t*>(P.views))[threadIdx.x] = src[threadIdx.x];
+        P.views = (const ViewDev*)(const void*)(seg + offsetof(ClearCullArgs, pack));
+    }
     // the two kinds of workgroup interleaved evenly along the launch order (all of one kind first would run them one after the other:
     // a launch's workgroups start in order)
     const uint32_t total = n_cull_blocks + n_clear_blocks;
@@ -2198,11 +2216,14 @@ void launch_put_views(const ViewPack& pack, uint32_t n, ViewDev* dst, hipStream_
     hipLaunchKernelGGL(k_put_views, dim3(1), dim3(256), 0, s, pack, n * (uint32_t)(sizeof(ViewDev) / 4), (uint32_t*)dst);
 }
 
-void launch_clear_cull(const FrameParams& p, uint32_t* zero, hipStream_t s, hipEvent_t start) {
+void launch_clear_cull(const FrameParams& p, uint32_t* zero, hipStream_t s, hipEvent_t start, const ViewPack* pack, uint32_t n_pack_views) {
     const size_t total = (size_t)p.n_views * p.n_tiles * p.bx_count * p.by_count;
     const unsigned n_cull = (unsigned)((total + 255) / 256), n_clear = 2048;
-    if (start) hipExtLaunchKernelGGL(k_clear_cull, dim3(n_cull + n_clear), dim3(256), 0, s, start, nullptr, 0, p, n_cull, n_clear, zero);
-    else hipLaunchKernelGGL(k_clear_cull, dim3(n_cull + n_clear), dim3(256), 0, s, p, n_cull, n_clear, zero);
+    static const ViewPack none{};
+    const ViewPack& pk = pack ? *pack : none;
+    const uint32_t words = pack ? n_pack_views * (uint32_t)(sizeof(ViewDev) / 4) : 0u;
+    if (start) hipExtLaunchKernelGGL(k_clear_cull, dim3(n_cull + n_clear), dim3(256), 0, s, start, nullptr, 0, p, n_cull, n_clear, zero, pk, words);
+    else hipLaunchKernelGGL(k_clear_cull, dim3(n_cull + n_clear), dim3(256), 0, s, p, n_cull, n_clear, zero, pk, words);
 }
 
 void launch_cull(const FrameParams& p, hipStream_t s) {
