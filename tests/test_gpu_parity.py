@@ -847,9 +847,11 @@ def test_random_frames(topo, orc):
     """Seeded sweep over camera poses and targets the hand-picked cases do not name: odd target sizes, steep pitches
     (ground filling the frame, triangles cut by the near plane), wide and narrow fields of view, eyes a few metres to tens
     of kilometres above the surface, all three view modes -- every frame bit-identical to the oracle's."""
-    rng = np.random.default_rng(20261004)
+    # (TOPO_FUZZ_FRAMES / TOPO_FUZZ_SEED: a longer or different sweep, run by hand on a GPU box)
+    rng = np.random.default_rng(int(os.environ.get("TOPO_FUZZ_SEED", "20261004")))
+    rng_split = np.random.default_rng(7)      # the occlusion split: off, inside the scene (far phase runs), the default (the host proves it empty)
     scenes = {}
-    for i in range(28):
+    for i in range(int(os.environ.get("TOPO_FUZZ_FRAMES", "600"))):
         tile = int(rng.choice([24, 40, 64, 96]))
         n_lat, n_lon = int(rng.integers(1, 3)), int(rng.integers(1, 3))
         dh = float(rng.choice([3.0, 12.0, 50.0, 50.0, 400.0, 5000.0, 40000.0]))
@@ -867,7 +869,9 @@ def test_random_frames(topo, orc):
         u, pu = sc.uniforms(W, H, yaw, pitch, fov, mode), topo.post_uniforms(W, H)
         g.update(W, H, u, pu)
         o.update(W, H, u, pu)
-        assert_same_frame(g.render(), o.render(), f"random frame {i}: tile {tile} {n_lat}x{n_lon} dh {dh} {W}x{H} yaw {yaw:.1f} pitch {pitch:.1f} fov {fov:.1f} mode {mode}")
+        split = float(rng_split.choice([0.0, 3000.0, 15000.0, 90000.0]))
+        g.set_occlusion_split(split)
+        assert_same_frame(g.render(), o.render(), f"random frame {i}: tile {tile} {n_lat}x{n_lon} dh {dh} {W}x{H} yaw {yaw:.1f} pitch {pitch:.1f} fov {fov:.1f} mode {mode} split {split}")
         assert (g.counters()["status"] & 1) == 0
 
 
