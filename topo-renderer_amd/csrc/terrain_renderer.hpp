@@ -152,7 +152,7 @@ class TerrainRenderer {
         uint64_t frames = 0;                  // frames submitted on this context
         hipEvent_t done = nullptr;
         bool timed = false, pending = false;
-        // pinned ring of the last kStatusRing frames' 16 counter words, each copied out in stream order behind its k_resolve;
+        // pinned ring of the last kStatusRing frames' 16 counter words, each stored by its frame's k_resolve (the bounds-checking build: copied out behind it);
         // frames [checked, submitted) have not been looked at by check_frames yet
         uint32_t* h_status = nullptr;
         uint64_t submitted = 0, checked = 0;
