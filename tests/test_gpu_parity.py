@@ -925,6 +925,29 @@ def test_timing_slots_select_events(topo, orc):
     assert g.timings()["total"] > 0.0
 
 
+def test_fall_back_paths_render_the_same_frames():
+    """The library's older ways of doing what stands around a frame's kernels stay selectable by environment (tools/README.md): the
+    view constants through the pinned ring or through k_put_views, the status words copied behind the frame, timing events as
+    markers, the far phase always launched, clear and cull as two launches.  Each is read once per process, so each gets a process
+    of its own (tests/env_paths_worker.py): every frame, depth image and counter set must hash to what the default path gives."""
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "env_paths_worker.py")
+
+    def run(extra):
+        env = dict(os.environ, **extra)
+        out = subprocess.run([sys.executable, worker], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, (extra, out.stderr[-2000:])
+        lines = [ln for ln in out.stdout.splitlines() if ln.startswith("SHA256 ")]
+        assert len(lines) == 1, (extra, out.stdout[-500:])
+        return lines[0]
+
+    want = run({})
+    for extra in ({"TOPO_VIEWS_IN_CULL": "0"}, {"TOPO_VIEWS_BY_COPY": "1"}, {"TOPO_STATUS_BY_COPY": "1"}, {"TOPO_EVENTS_BY_MARKER": "1"},
+                  {"TOPO_FAR_SKIP": "0"}, {"TOPO_FUSE_CLEAR_CULL": "0"}, {"TOPO_LOAD_FUSED": "0"}):
+        assert run(extra) == want, extra
+
+
 def test_render_device_equals_render(topo, orc):
     """topo_render_device (device outputs, stream-ordered) gives the bytes topo_render copies to the host; a padded pitch works."""
     import torch
