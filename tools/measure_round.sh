@@ -18,7 +18,7 @@ timeout -k 10 600 python3 bench.py > $O/bench_default.json 2> $O/bench_default.e
 TOPO_LOAD_FUSED=0 timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-pmc --steps 5 > $O/bench_c4_separate_load.json 2> $O/bench_c4_separate_load.err; echo "separate-load done"
 timeout -k 10 400 python3 bench.py --workload c5 --no-cpu-baseline --no-pmc --steps 2 --warmup 1 > $O/bench_c5.json 2> $O/bench_c5.err; echo "c5 done"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o c4 -- python3 $R/bench.py --workload c4 --no-cpu-baseline --no-pmc --no-host-path > $O/stats.log 2>&1; echo "stats done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o c4 -- python3 $R/bench.py --workload c4 --no-cpu-baseline --no-pmc --no-host-path --no-pipelined-extra > $O/stats.log 2>&1; echo "stats done"
 TOPO_SWEEP_DEG=5 rocprofv3 --kernel-trace --stats --output-format csv -d $O/sweep_stats -o sweep -- python3 $R/tools/sweep_normals_lds.py > $O/normals_lds_sweep.json 2> $O/sweep.err; echo "sweep done"
 cd $R
 find $O/stats -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;

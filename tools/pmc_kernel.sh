@@ -7,7 +7,7 @@ R=$(pwd)
 cd /tmp && export TMPDIR=/tmp
 n=0
 for grp in "$@"; do
-  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $R/gpurun_out/pmc_$TAG/$n -o p -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pmc > $R/gpurun_out/pmc_${TAG}_$n.log 2>&1
+  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $R/gpurun_out/pmc_$TAG/$n -o p -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pmc --no-host-path --no-pipelined-extra > $R/gpurun_out/pmc_${TAG}_$n.log 2>&1
   n=$((n+1))
 done
 python3 $R/tools/summarize_pmc.py $R/gpurun_out/pmc_$TAG

@@ -5,7 +5,7 @@ set -e
 TAG=$1; shift
 R=$(pwd)
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -o $TAG -- python3 $R/bench.py --no-cpu-baseline --no-pmc --steps 10 "$@" > $R/gpurun_out/prof_$TAG.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -o $TAG -- python3 $R/bench.py --no-cpu-baseline --no-pmc --no-host-path --no-pipelined-extra --steps 10 "$@" > $R/gpurun_out/prof_$TAG.log 2>&1
 python3 - <<PY
 import csv,glob
 f=glob.glob('$R/gpurun_out/prof_$TAG/**/*kernel_stats.csv',recursive=True)[0]
